@@ -1,0 +1,144 @@
+/*
+ * mpc_amd.h — C-ABI of libmpc_amd.so: the UR20 MPC inner numeric loop on MI355X (gfx950).
+ *
+ * The reference (canongun/MPC) has no FFI; its "operator API" for this path is a set of
+ * Python callables handed to scipy.optimize.minimize (ur_mpc.py:188-200).  Each entry point
+ * below names the reference callable it replaces.  Paths are relative to
+ * /root/reference/ur20_mpc_controller/ur20_mpc_controller/models/ :
+ *   MPC:<line> = ur_mpc.py, DYN:<line> = ur20_dynamics.py; NUMDIFF = scipy/optimize/_numdiff.py,
+ *   SLSQP = scipy/optimize/_slsqp_py.py (scipy 1.15.3, the third-party caller of the callables).
+ *
+ * Conventions
+ *   - all array arguments are DEVICE pointers (e.g. torch tensor.data_ptr()), fp64, owned by the
+ *     caller, laid out [N][...] with the scenario index slowest (each scenario's row contiguous);
+ *   - `stream` is a hipStream_t passed as void*; work is enqueued asynchronously on it;
+ *   - every function returns MPC_OK (0) or a negative mpc_status; none throws;
+ *     mpc_last_error() gives the text of the last failure on that context;
+ *   - one context per caller thread and device; a context is not re-entrant.
+ *
+ * Sizes: H = horizon, n = 6*H decision variables, m = 12*(H+1) inequality rows.
+ */
+#ifndef MPC_AMD_H
+#define MPC_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MPC_AMD_ABI_VERSION 1
+#define MPC_MAX_HORIZON 255
+
+typedef enum mpc_status {
+    MPC_OK = 0,
+    MPC_ERR_INVALID_ARG = -1,
+    MPC_ERR_HIP = -2,
+    MPC_ERR_UNSUPPORTED = -3,
+    MPC_ERR_NO_PARAMS = -4,
+    MPC_ERR_NO_DEVICE = -5
+} mpc_status;
+
+typedef enum mpc_algo {
+    MPC_ALGO_AUTO = 0,
+    /* one workgroup per (scenario, perturbation group), one lane per horizon step, full rollouts,
+     * strict (uncontracted) fp64 arithmetic in the oracle's evaluation order */
+    MPC_ALGO_ROLLOUT = 1,
+    /* one workgroup per scenario: base rollout once, then every perturbed rollout restarts from
+     * the shared prefix at the perturbed step */
+    MPC_ALGO_PREFIX = 2
+} mpc_algo;
+
+typedef struct mpc_ctx mpc_ctx;
+
+/* Everything URMPC.__init__ / UR20Dynamics.__init__ read from the parameter server
+ * (MPC:29-81, DYN:18-47) plus the kinematic table that stands in for MoveIt (DYN:82). */
+typedef struct mpc_params {
+    int32_t horizon;        /* MPC:29 */
+    int32_t algo;           /* mpc_algo */
+    double dt_cost;         /* UR20Dynamics.dt, step of the rollout inside _cost_function (MPC:686, DYN:19,97-98) */
+    double dt_con;          /* URMPC.dt, step of predict_trajectory inside the constraint (MPC:30,705) */
+    double w_position;      /* MPC:39 */
+    double w_orientation;   /* MPC:40 */
+    double w_control;       /* MPC:41 */
+    double w_smooth;        /* MPC:42 */
+    double w_damping;       /* MPC:59 */
+    double w_linear;        /* MPC:45 */
+    double w_angular;       /* MPC:46 */
+    double terminal_factor; /* 2.0, MPC:373 */
+    double fd_eps;          /* 1e-3, options['eps'] MPC:197 -> abs_step of NUMDIFF:498-524 */
+    double q_lo[6];         /* DYN:31-38 */
+    double q_hi[6];
+    double v_lim[6];        /* DYN:40-47; also the bounds on x, MPC:420-430 */
+    /* standard-DH table of the arm; ca/sa = cos/sin of the link twists (exact 0/+-1 for a UR) */
+    double dh_a[6], dh_d[6], dh_ca[6], dh_sa[6];
+    double base_c, base_s;  /* yaw of the DH base in the frame the Jacobian is expressed in */
+    double tool[3];         /* tool0 -> tip translation, in the tool0 frame */
+} mpc_params;
+
+/* Per-scenario inputs of one batch: what compute_control assembles before it calls minimize
+ * (MPC:148-157).  Rows: state0 = [q, dq, ee_pos, ee_rpy] (DYN:49-56); target = [pos, rpy];
+ * base_traj[k] = [position, orientation, linear_velocity, angular_velocity] of
+ * predict_base_motion's entry k (MPC:592-597,645-650); Jc = _J_cached row-major (MPC:157);
+ * u_prev/has_prev = previous_control and whether the attribute exists yet (MPC:209,313). */
+typedef struct mpc_scenarios {
+    int32_t count;             /* N */
+    int32_t reserved;
+    const double *state0;      /* [N][18] */
+    const double *target;      /* [N][6]  */
+    const double *base_traj;   /* [N][H][12] */
+    const double *Jc;          /* [N][36] */
+    const double *u_prev;      /* [N][6] or NULL */
+    const uint8_t *has_prev;   /* [N] or NULL (= all zero) */
+} mpc_scenarios;
+
+/* version of this ABI (MPC_AMD_ABI_VERSION of the library that was loaded) */
+int mpc_abi_version(void);
+
+/* Create a context bound to HIP device `device` for horizon `horizon` and up to `max_scenarios`
+ * scenarios per call (sizes the internal workspace).  Replaces URMPC.__init__ (MPC:15-81). */
+int mpc_ctx_create(int device, int horizon, int max_scenarios, mpc_ctx **out);
+void mpc_ctx_destroy(mpc_ctx *ctx);
+
+/* Weights, limits, kinematic table and the decay table decay[k] = 0.95**k, k < H (MPC:294),
+ * evaluated by the host so that it is bit-identical to CPython's pow. */
+int mpc_set_params(mpc_ctx *ctx, const mpc_params *params, const double *decay_host, int n_decay);
+
+/* f(x) and c(x) for N scenarios: replaces URMPC._cost_function (MPC:665-692) and the
+ * dynamics_constraint closure (MPC:388-411), i.e. SLSQP's mode-1 request (SLSQP:434-436).
+ *   x [N][n] -> cost [N], con [N][m] (con may be NULL). */
+int mpc_eval(mpc_ctx *ctx, const mpc_scenarios *sc, const double *x, double *cost, double *con,
+             void *stream);
+
+/* One "eval" per scenario: f, c, the forward-difference gradient and constraint Jacobian that
+ * scipy builds around the two callables (approx_derivative '2-point', abs_step = fd_eps, step
+ * sign flipped at the upper bound: NUMDIFF:44-72,498-524,584-625; wiring SLSQP:299-313,381-387),
+ * i.e. SLSQP's mode -1 request (SLSQP:438-440).
+ *   x [N][n] -> cost [N], grad [N][n], con [N][m],
+ *   con_jac [N][n][m]: per scenario COLUMN-major m x n (con_jac[s][i][r] = d c_r / d x_i), the
+ *   layout the Fortran core of SLSQP consumes (a(la, n+1), SLSQP:509).  grad/con/con_jac may be NULL. */
+int mpc_eval_fd(mpc_ctx *ctx, const mpc_scenarios *sc, const double *x, double *cost, double *grad,
+                double *con, double *con_jac, void *stream);
+
+/* Batched 6x6 geometric Jacobian, row-major, rows 0-2 linear / 3-5 angular: replaces
+ * UR20Dynamics.get_jacobian (DYN:74-87; MoveIt's getJacobian in the reference).  q [N][6] -> J [N][36]. */
+int mpc_jacobian(mpc_ctx *ctx, int count, const double *q, double *J, void *stream);
+
+/* Batched forward kinematics of the same chain: tip position and roll/pitch/yaw ('sxyz'), what
+ * the action server reads from MoveIt to fill ee_pose (mpc_action_server.py:57-75).
+ * q [N][6] -> pose [N][6] = [x,y,z,roll,pitch,yaw]. */
+int mpc_fk(mpc_ctx *ctx, int count, const double *q, double *pose, void *stream);
+
+/* Batched platform predictor: replaces URMPC._predict_base_dynamic (MPC:606-651).
+ * base [N][12] = [position, orientation, linear_velocity, angular_velocity] (base_observer.py:55-62),
+ * dyn_host[6] = {mass, I_z, k_v, k_omega, tau_linear, tau_angular} (HOST pointer) -> base_traj [N][H][12]. */
+int mpc_predict_base_dynamic(mpc_ctx *ctx, int count, const double *base, const double *dyn_host,
+                             double *base_traj, void *stream);
+
+/* Text of the last error recorded on ctx (or on the calling thread when ctx is NULL). */
+const char *mpc_last_error(const mpc_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MPC_AMD_H */

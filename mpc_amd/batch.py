@@ -1,0 +1,200 @@
+"""Host-side batch interface: torch tensors as device buffers, libmpc_amd.so for every number.
+
+Torch is plumbing here (device memory, streams); nothing is computed with torch ops and there is
+no fallback when the library or the GPU is missing."""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Optional
+
+import numpy as np
+import torch
+
+from . import _ffi
+from .params import MpcParams
+
+
+def _dev_index(device) -> int:
+    if isinstance(device, int):
+        return device
+    d = torch.device(device)
+    if d.type != "cuda":
+        raise ValueError(f"mpc_amd runs on a HIP device only, got {d}")
+    return d.index if d.index is not None else torch.cuda.current_device()
+
+
+@dataclass
+class ScenarioBatch:
+    """Per-scenario inputs that ``compute_control`` assembles before calling ``minimize``
+    (ur_mpc.py:148-157), N scenarios, each row contiguous, fp64 on the device."""
+
+    state0: torch.Tensor                      # [N,18] = [q, dq, ee_pos, ee_rpy]  (ur20_dynamics.py:49-56)
+    target: torch.Tensor                      # [N,6]  = [pos, rpy]
+    base_traj: torch.Tensor                   # [N,H,12] = [position, orientation, lin vel, ang vel] per step
+    Jc: torch.Tensor                          # [N,36] = _J_cached, row-major (ur_mpc.py:157)
+    u_prev: Optional[torch.Tensor] = None     # [N,6]  previous_control
+    has_prev: Optional[torch.Tensor] = None   # [N] uint8: does previous_control exist yet (ur_mpc.py:313)
+
+    @property
+    def count(self) -> int:
+        return int(self.state0.shape[0])
+
+    @classmethod
+    def from_numpy(cls, device, state0, target, base_traj, Jc, u_prev=None, has_prev=None) -> "ScenarioBatch":
+        dev = torch.device("cuda", _dev_index(device))
+
+        def up(a, dtype=torch.float64):
+            return None if a is None else torch.as_tensor(np.ascontiguousarray(a), dtype=dtype).to(dev)
+
+        N = np.asarray(state0).reshape(-1, 18).shape[0]
+        return cls(up(np.asarray(state0).reshape(N, 18)), up(np.asarray(target).reshape(N, 6)),
+                   up(np.asarray(base_traj).reshape(N, -1, 12)), up(np.asarray(Jc).reshape(N, 36)),
+                   up(None if u_prev is None else np.asarray(u_prev).reshape(N, 6)),
+                   up(None if has_prev is None else np.asarray(has_prev).reshape(N), torch.uint8))
+
+    def slice(self, lo: int, hi: int) -> "ScenarioBatch":
+        f = lambda t: None if t is None else t[lo:hi]
+        return ScenarioBatch(f(self.state0), f(self.target), f(self.base_traj), f(self.Jc), f(self.u_prev),
+                             f(self.has_prev))
+
+
+@dataclass
+class EvalResult:
+    cost: torch.Tensor                 # [N]
+    grad: Optional[torch.Tensor]       # [N,n]
+    con: Optional[torch.Tensor]        # [N,m]
+    con_jac: Optional[torch.Tensor]    # [N,n,m]: per scenario column-major m x n
+
+    def jac_for_scipy(self, i: int) -> np.ndarray:
+        """(m, n) Fortran-ordered array of scenario i, the layout SLSQP's core consumes."""
+        return self.con_jac[i].cpu().numpy().T
+
+
+class MpcContext:
+    """One libmpc_amd context: fixed horizon, parameters and device."""
+
+    def __init__(self, params: MpcParams, max_scenarios: int, device=0):
+        self._lib = _ffi.load()
+        self.params = params
+        self.device_index = _dev_index(device)
+        self.device = torch.device("cuda", self.device_index)
+        self.max_scenarios = int(max_scenarios)
+        self.H, self.n, self.m = params.horizon, params.n, params.m
+        self._ctx = C.c_void_p()
+        _ffi.check(None, self._lib.mpc_ctx_create(self.device_index, params.horizon, self.max_scenarios,
+                                                  C.byref(self._ctx)))
+        self.set_params(params)
+
+    def set_params(self, params: MpcParams):
+        if params.horizon != self.H:
+            raise ValueError("horizon is fixed per context")
+        cp = params.to_c()
+        decay = params.decay_table()
+        _ffi.check(self._ctx, self._lib.mpc_set_params(self._ctx, C.byref(cp),
+                                                       decay.ctypes.data_as(C.POINTER(C.c_double)), len(decay)))
+        self.params = params
+
+    def close(self):
+        if getattr(self, "_ctx", None) is not None and self._ctx.value:
+            self._lib.mpc_ctx_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- argument plumbing ---------------------------------------------------------------
+    def _chk(self, t: Optional[torch.Tensor], shape, name, dtype=torch.float64, optional=False):
+        if t is None:
+            if optional:
+                return None
+            raise ValueError(f"{name} is required")
+        if not (t.is_cuda and t.device.index == self.device_index):
+            raise ValueError(f"{name} must live on {self.device}")
+        if t.dtype != dtype or not t.is_contiguous():
+            raise ValueError(f"{name} must be contiguous {dtype}")
+        if tuple(t.shape) != tuple(shape):
+            raise ValueError(f"{name} has shape {tuple(t.shape)}, expected {tuple(shape)}")
+        return t.data_ptr()
+
+    def _scen_c(self, sc: ScenarioBatch) -> _ffi.MpcScenariosC:
+        N = sc.count
+        if N > self.max_scenarios:
+            raise ValueError(f"{N} scenarios > max_scenarios {self.max_scenarios}")
+        c = _ffi.MpcScenariosC()
+        c.count = N
+        c.state0 = self._chk(sc.state0, (N, 18), "state0")
+        c.target = self._chk(sc.target, (N, 6), "target")
+        c.base_traj = self._chk(sc.base_traj, (N, self.H, 12), "base_traj")
+        c.Jc = self._chk(sc.Jc, (N, 36), "Jc")
+        c.u_prev = self._chk(sc.u_prev, (N, 6), "u_prev", optional=True)
+        c.has_prev = self._chk(sc.has_prev, (N,), "has_prev", dtype=torch.uint8, optional=True)
+        return c
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _new(self, *shape):
+        return torch.empty(shape, dtype=torch.float64, device=self.device)
+
+    # ---- the hot path ----------------------------------------------------------------------
+    def eval(self, sc: ScenarioBatch, x: torch.Tensor, want_con: bool = True, out: Optional[EvalResult] = None):
+        """f(x), c(x): ``_cost_function`` (ur_mpc.py:665-692) and ``dynamics_constraint`` (ur_mpc.py:388-411)."""
+        N = sc.count
+        scc = self._scen_c(sc)
+        xp = self._chk(x, (N, self.n), "x")
+        cost = out.cost if out is not None else self._new(N)
+        con = (out.con if out is not None else self._new(N, self.m)) if want_con else None
+        self._chk(cost, (N,), "cost")
+        cp = self._chk(con, (N, self.m), "con", optional=True)
+        _ffi.check(self._ctx, self._lib.mpc_eval(self._ctx, C.byref(scc), xp, cost.data_ptr(), cp, self._stream()))
+        return EvalResult(cost, None, con, None)
+
+    def eval_fd(self, sc: ScenarioBatch, x: torch.Tensor, want_grad: bool = True, want_con: bool = True,
+                want_jac: bool = True, out: Optional[EvalResult] = None) -> EvalResult:
+        """f, c and scipy's forward-difference grad f and dc/dx (one "eval" per scenario)."""
+        N = sc.count
+        scc = self._scen_c(sc)
+        xp = self._chk(x, (N, self.n), "x")
+        cost = out.cost if out is not None else self._new(N)
+        grad = (out.grad if out is not None and out.grad is not None else self._new(N, self.n)) if want_grad else None
+        con = (out.con if out is not None and out.con is not None else self._new(N, self.m)) if want_con else None
+        jac = (out.con_jac if out is not None and out.con_jac is not None
+               else self._new(N, self.n, self.m)) if want_jac else None
+        self._chk(cost, (N,), "cost")
+        gp = self._chk(grad, (N, self.n), "grad", optional=True)
+        cp = self._chk(con, (N, self.m), "con", optional=True)
+        jp = self._chk(jac, (N, self.n, self.m), "con_jac", optional=True)
+        _ffi.check(self._ctx, self._lib.mpc_eval_fd(self._ctx, C.byref(scc), xp, cost.data_ptr(), gp, cp, jp,
+                                                    self._stream()))
+        return EvalResult(cost, grad, con, jac)
+
+    # ---- the steps either side of it -------------------------------------------------------
+    def jacobian(self, q: torch.Tensor) -> torch.Tensor:
+        """Batched ``get_jacobian`` (ur20_dynamics.py:74-87): q [N,6] -> J [N,6,6]."""
+        N = int(q.shape[0])
+        qp = self._chk(q, (N, 6), "q")
+        J = self._new(N, 6, 6)
+        _ffi.check(self._ctx, self._lib.mpc_jacobian(self._ctx, N, qp, J.data_ptr(), self._stream()))
+        return J
+
+    def fk(self, q: torch.Tensor) -> torch.Tensor:
+        """Batched tip pose [x,y,z,roll,pitch,yaw]: q [N,6] -> [N,6]."""
+        N = int(q.shape[0])
+        qp = self._chk(q, (N, 6), "q")
+        pose = self._new(N, 6)
+        _ffi.check(self._ctx, self._lib.mpc_fk(self._ctx, N, qp, pose.data_ptr(), self._stream()))
+        return pose
+
+    def predict_base_dynamic(self, base: torch.Tensor) -> torch.Tensor:
+        """Batched ``_predict_base_dynamic`` (ur_mpc.py:606-651): base [N,12] -> [N,H,12]."""
+        N = int(base.shape[0])
+        bp = self._chk(base, (N, 12), "base")
+        out = self._new(N, self.H, 12)
+        dyn = self.params.base_dyn_array()
+        _ffi.check(self._ctx, self._lib.mpc_predict_base_dynamic(
+            self._ctx, N, bp, dyn.ctypes.data_as(C.POINTER(C.c_double)), out.data_ptr(), self._stream()))
+        return out

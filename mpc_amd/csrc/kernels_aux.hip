@@ -1,0 +1,112 @@
+// Per-scenario helper kernels either side of the hot path: Jacobian / forward kinematics of the
+// arm (the MoveIt calls of the reference, DYN:82 and mpc_action_server.py:57-75) and the platform
+// predictor (MPC:606-651).  One thread per scenario, rows contiguous per scenario.
+// Compiled with -ffp-contract=off (same evaluation order as the CPU oracle).
+#include "mpc_device.hpp"
+#include "mpc_kernels.hpp"
+
+namespace {
+
+using namespace mpcdev;
+
+__global__ void jacobian_kernel(const mpc_params P, int N, const double *__restrict__ q, double *__restrict__ Jout)
+{
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= N) return;
+    double qq[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) qq[j] = q[(size_t)s * 6 + j];
+    Chain C;
+    ur_chain(P, qq, C);
+    double J[6][6];
+    chain_jacobian(C, J);
+#pragma unroll
+    for (int r = 0; r < 6; ++r)
+#pragma unroll
+        for (int c = 0; c < 6; ++c) Jout[(size_t)s * 36 + 6 * r + c] = J[r][c];
+}
+
+__global__ void fk_kernel(const mpc_params P, int N, const double *__restrict__ q, double *__restrict__ pose)
+{
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= N) return;
+    double qq[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) qq[j] = q[(size_t)s * 6 + j];
+    Chain C;
+    ur_chain(P, qq, C);
+    // roll/pitch/yaw of R, static 'sxyz' axes (tf.transformations.euler_from_matrix)
+    const double cy = sqrt(C.R[0][0] * C.R[0][0] + C.R[1][0] * C.R[1][0]);
+    double roll, pitch, yaw;
+    if (cy > 1e-12) {
+        roll = atan2(C.R[2][1], C.R[2][2]);
+        pitch = atan2(-C.R[2][0], cy);
+        yaw = atan2(C.R[1][0], C.R[0][0]);
+    } else {
+        roll = atan2(-C.R[1][2], C.R[1][1]);
+        pitch = atan2(-C.R[2][0], cy);
+        yaw = 0.0;
+    }
+    double *out = pose + (size_t)s * 6;
+    out[0] = C.pe[0]; out[1] = C.pe[1]; out[2] = C.pe[2];
+    out[3] = roll; out[4] = pitch; out[5] = yaw;
+}
+
+struct BaseDyn { double mass, Iz, k_v, k_omega, tau_l, tau_a; };
+
+// MPC:606-651; v_cmd / omega_cmd default to the current v / omega (MPC:624-625)
+__global__ void predict_base_dynamic_kernel(int N, int H, double dt, const BaseDyn D,
+                                            const double *__restrict__ base, double *__restrict__ out)
+{
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= N) return;
+    const double *b = base + (size_t)s * 12;
+    double px = b[0], py = b[1], pz = b[2];
+    double yaw = b[5], v = b[6], w = b[11];
+    const double v_cmd = v, w_cmd = w;
+    for (int k = 0; k < H; ++k) {
+        const double force = (D.mass / D.tau_l) * (v_cmd - v);
+        const double acc = (force - D.k_v * v) / D.mass;
+        v = v + acc * dt;
+        const double torque = (D.Iz / D.tau_a) * (w_cmd - w);
+        const double alpha = (torque - D.k_omega * w) / D.Iz;
+        w = w + alpha * dt;
+        yaw = yaw + w * dt;
+        double sn, cs;
+        sincos(yaw, &sn, &cs);
+        const double vx = v * cs, vy = v * sn;
+        px = px + vx * dt; py = py + vy * dt; pz = pz + 0.0 * dt;
+        double *r = out + ((size_t)s * H + k) * 12;
+        r[0] = px; r[1] = py; r[2] = pz;
+        r[3] = 0.0; r[4] = 0.0; r[5] = yaw;
+        r[6] = vx; r[7] = vy; r[8] = 0.0;
+        r[9] = 0.0; r[10] = 0.0; r[11] = w;
+    }
+}
+
+}  // namespace
+
+namespace mpck {
+
+hipError_t launch_jacobian(const mpc_params &P, int N, const double *q, double *J, hipStream_t stream)
+{
+    hipLaunchKernelGGL(jacobian_kernel, dim3((N + 63) / 64), dim3(64), 0, stream, P, N, q, J);
+    return hipGetLastError();
+}
+
+hipError_t launch_fk(const mpc_params &P, int N, const double *q, double *pose, hipStream_t stream)
+{
+    hipLaunchKernelGGL(fk_kernel, dim3((N + 63) / 64), dim3(64), 0, stream, P, N, q, pose);
+    return hipGetLastError();
+}
+
+hipError_t launch_predict_base_dynamic(int N, int H, double dt, const double *base, const double (&dyn)[6],
+                                       double *out, hipStream_t stream)
+{
+    BaseDyn D{dyn[0], dyn[1], dyn[2], dyn[3], dyn[4], dyn[5]};
+    hipLaunchKernelGGL(predict_base_dynamic_kernel, dim3((N + 63) / 64), dim3(64), 0, stream, N, H, dt, D, base,
+                       out);
+    return hipGetLastError();
+}
+
+}  // namespace mpck

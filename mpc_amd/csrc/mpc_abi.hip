@@ -1,0 +1,229 @@
+// C-ABI of libmpc_amd.so (declared in include/mpc_amd.h): context, argument checks, launches.
+// No torch types, no exceptions across the boundary, nothing is computed on the host.
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+#include <hip/hip_runtime.h>
+
+#include "mpc_amd.h"
+#include "mpc_kernels.hpp"
+
+struct mpc_ctx {
+    int device = 0;
+    int horizon = 0;
+    int max_scenarios = 0;
+    bool have_params = false;
+    mpc_params params{};
+    double *d_decay = nullptr;  // [H]
+    double *d_fvals = nullptr;  // [max_scenarios][n+1], MPC_ALGO_ROLLOUT only
+    char err[512] = {0};
+};
+
+namespace {
+
+thread_local char g_err[512] = {0};
+
+int fail(mpc_ctx *ctx, int code, const char *fmt, ...)
+{
+    char *dst = ctx ? ctx->err : g_err;
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(dst, 512, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+int hip_fail(mpc_ctx *ctx, hipError_t e, const char *what)
+{
+    return fail(ctx, MPC_ERR_HIP, "%s: %s", what, hipGetErrorString(e));
+}
+
+#define MPC_HIP(ctx, call)                                   \
+    do {                                                     \
+        hipError_t e_ = (call);                              \
+        if (e_ != hipSuccess) return hip_fail(ctx, e_, #call); \
+    } while (0)
+
+int check_ready(mpc_ctx *ctx)
+{
+    if (!ctx) return fail(nullptr, MPC_ERR_INVALID_ARG, "ctx is NULL");
+    if (!ctx->have_params) return fail(ctx, MPC_ERR_NO_PARAMS, "mpc_set_params has not been called");
+    return MPC_OK;
+}
+
+int check_scenarios(mpc_ctx *ctx, const mpc_scenarios *sc, const double *x)
+{
+    if (!sc) return fail(ctx, MPC_ERR_INVALID_ARG, "scenarios is NULL");
+    if (sc->count < 0 || sc->count > ctx->max_scenarios)
+        return fail(ctx, MPC_ERR_INVALID_ARG, "scenario count %d outside [0, %d]", sc->count, ctx->max_scenarios);
+    if (sc->count == 0) return MPC_OK;
+    if (!sc->state0 || !sc->target || !sc->base_traj || !sc->Jc || !x)
+        return fail(ctx, MPC_ERR_INVALID_ARG, "state0/target/base_traj/Jc/x must be non-NULL");
+    if (sc->has_prev && !sc->u_prev) return fail(ctx, MPC_ERR_INVALID_ARG, "has_prev given without u_prev");
+    return MPC_OK;
+}
+
+int resolve_algo(const mpc_ctx *ctx)
+{
+    int a = ctx->params.algo;
+    if (a == MPC_ALGO_AUTO) a = mpck::prefix_supported(ctx->params) ? MPC_ALGO_PREFIX : MPC_ALGO_ROLLOUT;
+    return a;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mpc_abi_version(void) { return MPC_AMD_ABI_VERSION; }
+
+const char *mpc_last_error(const mpc_ctx *ctx) { return ctx ? ctx->err : g_err; }
+
+int mpc_ctx_create(int device, int horizon, int max_scenarios, mpc_ctx **out)
+{
+    if (!out) return fail(nullptr, MPC_ERR_INVALID_ARG, "out is NULL");
+    *out = nullptr;
+    if (horizon <= 0) return fail(nullptr, MPC_ERR_INVALID_ARG, "Horizon must be positive");  // MPC:33-34
+    if (horizon > MPC_MAX_HORIZON)
+        return fail(nullptr, MPC_ERR_UNSUPPORTED, "horizon %d > MPC_MAX_HORIZON %d", horizon, MPC_MAX_HORIZON);
+    if (max_scenarios <= 0) return fail(nullptr, MPC_ERR_INVALID_ARG, "max_scenarios must be positive");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+        return fail(nullptr, MPC_ERR_NO_DEVICE, "no HIP device visible: this library has no CPU path");
+    if (device < 0 || device >= ndev)
+        return fail(nullptr, MPC_ERR_INVALID_ARG, "device %d outside [0, %d)", device, ndev);
+    mpc_ctx *ctx = new (std::nothrow) mpc_ctx();
+    if (!ctx) return fail(nullptr, MPC_ERR_HIP, "out of host memory");
+    ctx->device = device;
+    ctx->horizon = horizon;
+    ctx->max_scenarios = max_scenarios;
+    hipError_t e = hipSetDevice(device);
+    if (e == hipSuccess) e = hipMalloc(&ctx->d_decay, sizeof(double) * (size_t)horizon);
+    if (e == hipSuccess)
+        e = hipMalloc(&ctx->d_fvals, sizeof(double) * (size_t)max_scenarios * (size_t)(6 * horizon + 1));
+    if (e != hipSuccess) {
+        int rc = hip_fail(nullptr, e, "mpc_ctx_create");
+        mpc_ctx_destroy(ctx);
+        return rc;
+    }
+    *out = ctx;
+    return MPC_OK;
+}
+
+void mpc_ctx_destroy(mpc_ctx *ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->d_decay) (void)hipFree(ctx->d_decay);
+    if (ctx->d_fvals) (void)hipFree(ctx->d_fvals);
+    delete ctx;
+}
+
+int mpc_set_params(mpc_ctx *ctx, const mpc_params *p, const double *decay_host, int n_decay)
+{
+    if (!ctx) return fail(nullptr, MPC_ERR_INVALID_ARG, "ctx is NULL");
+    if (!p || !decay_host) return fail(ctx, MPC_ERR_INVALID_ARG, "params/decay is NULL");
+    if (p->horizon != ctx->horizon)
+        return fail(ctx, MPC_ERR_INVALID_ARG, "params.horizon %d != context horizon %d", p->horizon, ctx->horizon);
+    if (n_decay != ctx->horizon) return fail(ctx, MPC_ERR_INVALID_ARG, "decay table must have H entries");
+    if (!(p->dt_cost > 0.0) || !(p->dt_con > 0.0))
+        return fail(ctx, MPC_ERR_INVALID_ARG, "Time step must be positive");  // MPC:35-36
+    if (!(p->fd_eps > 0.0)) return fail(ctx, MPC_ERR_INVALID_ARG, "fd_eps must be positive");
+    if (p->algo < MPC_ALGO_AUTO || p->algo > MPC_ALGO_PREFIX)
+        return fail(ctx, MPC_ERR_INVALID_ARG, "unknown algo %d", p->algo);
+    for (int j = 0; j < 6; ++j) {
+        if (!(p->q_lo[j] <= p->q_hi[j]) || !(p->v_lim[j] > 0.0))
+            return fail(ctx, MPC_ERR_INVALID_ARG, "joint %d: limits are not ordered / positive", j);
+    }
+    const double *all = reinterpret_cast<const double *>(&p->dt_cost);
+    const size_t ndbl = (sizeof(mpc_params) - offsetof(mpc_params, dt_cost)) / sizeof(double);
+    for (size_t i = 0; i < ndbl; ++i)
+        if (!std::isfinite(all[i])) return fail(ctx, MPC_ERR_INVALID_ARG, "params contain a non-finite value");
+    if (p->algo == MPC_ALGO_PREFIX && !mpck::prefix_supported(*p))
+        return fail(ctx, MPC_ERR_UNSUPPORTED, "MPC_ALGO_PREFIX does not support these parameters");
+    MPC_HIP(ctx, hipSetDevice(ctx->device));
+    MPC_HIP(ctx, hipMemcpy(ctx->d_decay, decay_host, sizeof(double) * (size_t)n_decay, hipMemcpyHostToDevice));
+    ctx->params = *p;
+    ctx->have_params = true;
+    return MPC_OK;
+}
+
+int mpc_eval(mpc_ctx *ctx, const mpc_scenarios *sc, const double *x, double *cost, double *con, void *stream)
+{
+    int rc = check_ready(ctx);
+    if (rc) return rc;
+    rc = check_scenarios(ctx, sc, x);
+    if (rc) return rc;
+    if (!cost) return fail(ctx, MPC_ERR_INVALID_ARG, "cost is NULL");
+    if (sc->count == 0) return MPC_OK;
+    MPC_HIP(ctx, hipSetDevice(ctx->device));
+    MPC_HIP(ctx, mpck::launch_rollout(ctx->params, ctx->d_decay, *sc, x, cost, 1, con, nullptr, 0,
+                                      static_cast<hipStream_t>(stream)));
+    return MPC_OK;
+}
+
+int mpc_eval_fd(mpc_ctx *ctx, const mpc_scenarios *sc, const double *x, double *cost, double *grad, double *con,
+                double *con_jac, void *stream)
+{
+    int rc = check_ready(ctx);
+    if (rc) return rc;
+    rc = check_scenarios(ctx, sc, x);
+    if (rc) return rc;
+    if (!cost) return fail(ctx, MPC_ERR_INVALID_ARG, "cost is NULL");
+    if (sc->count == 0) return MPC_OK;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    MPC_HIP(ctx, hipSetDevice(ctx->device));
+    if (resolve_algo(ctx) == MPC_ALGO_PREFIX) {
+        MPC_HIP(ctx, mpck::launch_prefix(ctx->params, ctx->d_decay, *sc, x, cost, grad, con, con_jac, st));
+        return MPC_OK;
+    }
+    const int n = 6 * ctx->horizon;
+    MPC_HIP(ctx, mpck::launch_rollout(ctx->params, ctx->d_decay, *sc, x, ctx->d_fvals, n + 1, con, con_jac, n, st));
+    MPC_HIP(ctx, mpck::launch_fd_finalize(ctx->params, sc->count, x, ctx->d_fvals, cost, grad, st));
+    return MPC_OK;
+}
+
+int mpc_jacobian(mpc_ctx *ctx, int count, const double *q, double *J, void *stream)
+{
+    int rc = check_ready(ctx);
+    if (rc) return rc;
+    if (count < 0 || (count > 0 && (!q || !J))) return fail(ctx, MPC_ERR_INVALID_ARG, "bad count / NULL q or J");
+    if (count == 0) return MPC_OK;
+    MPC_HIP(ctx, hipSetDevice(ctx->device));
+    MPC_HIP(ctx, mpck::launch_jacobian(ctx->params, count, q, J, static_cast<hipStream_t>(stream)));
+    return MPC_OK;
+}
+
+int mpc_fk(mpc_ctx *ctx, int count, const double *q, double *pose, void *stream)
+{
+    int rc = check_ready(ctx);
+    if (rc) return rc;
+    if (count < 0 || (count > 0 && (!q || !pose))) return fail(ctx, MPC_ERR_INVALID_ARG, "bad count / NULL q or pose");
+    if (count == 0) return MPC_OK;
+    MPC_HIP(ctx, hipSetDevice(ctx->device));
+    MPC_HIP(ctx, mpck::launch_fk(ctx->params, count, q, pose, static_cast<hipStream_t>(stream)));
+    return MPC_OK;
+}
+
+int mpc_predict_base_dynamic(mpc_ctx *ctx, int count, const double *base, const double *dyn_host,
+                             double *base_traj, void *stream)
+{
+    int rc = check_ready(ctx);
+    if (rc) return rc;
+    if (count < 0 || !dyn_host || (count > 0 && (!base || !base_traj)))
+        return fail(ctx, MPC_ERR_INVALID_ARG, "bad count / NULL base, dyn or base_traj");
+    for (int i = 0; i < 6; ++i)
+        if (!std::isfinite(dyn_host[i]) || (i != 2 && i != 3 && !(dyn_host[i] > 0.0)))
+            return fail(ctx, MPC_ERR_INVALID_ARG, "base dynamics: mass, I_z and the lags must be positive");
+    if (count == 0) return MPC_OK;
+    double dyn[6];
+    std::memcpy(dyn, dyn_host, sizeof(dyn));
+    MPC_HIP(ctx, hipSetDevice(ctx->device));
+    MPC_HIP(ctx, mpck::launch_predict_base_dynamic(count, ctx->horizon, ctx->params.dt_con, base, dyn, base_traj,
+                                                   static_cast<hipStream_t>(stream)));
+    return MPC_OK;
+}
+
+}  // extern "C"

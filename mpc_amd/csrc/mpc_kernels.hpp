@@ -1,0 +1,40 @@
+// Host-side launchers of the gfx950 kernels (one translation unit per arithmetic mode).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "mpc_amd.h"
+
+namespace mpck {
+
+// MPC_ALGO_ROLLOUT: one workgroup per (scenario, perturbation group), one lane per horizon step.
+// Writes f of rollout i (0 = unperturbed, v+1 = variable v stepped) to fvals[s*fstride + i];
+// the unperturbed rollout writes con[s][m]; perturbed rollout v writes column v of jac[s][n][m].
+hipError_t launch_rollout(const mpc_params &P, const double *decay, const mpc_scenarios &sc, const double *x,
+                          double *fvals, int fstride, double *con, double *jac, int n_pert,
+                          hipStream_t stream);
+
+// grad[s][v] = (fvals[s][v+1] - fvals[s][0]) / dx_v, cost[s] = fvals[s][0]  (NUMDIFF:594-619)
+hipError_t launch_fd_finalize(const mpc_params &P, int N, const double *x, const double *fvals, double *cost,
+                              double *grad, hipStream_t stream);
+
+// MPC_ALGO_PREFIX: one workgroup per scenario, shared-prefix perturbed rollouts.
+hipError_t launch_prefix(const mpc_params &P, const double *decay, const mpc_scenarios &sc, const double *x,
+                         double *cost, double *grad, double *con, double *jac, hipStream_t stream);
+bool prefix_supported(const mpc_params &P);
+
+hipError_t launch_jacobian(const mpc_params &P, int N, const double *q, double *J, hipStream_t stream);
+hipError_t launch_fk(const mpc_params &P, int N, const double *q, double *pose, hipStream_t stream);
+hipError_t launch_predict_base_dynamic(int N, int H, double dt, const double *base, const double (&dyn)[6],
+                                       double *out, hipStream_t stream);
+
+// Blocks b and b+8 share an XCD (round-robin dispatch): give every XCD one contiguous range of
+// logical ids so that the workgroups of one scenario hit the same L2.  Bijective for any grid.
+__device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nwg)
+{
+    const unsigned xcd = bid & 7u, q = nwg >> 3, r = nwg & 7u;
+    const unsigned start = (xcd < r) ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q;
+    return start + (bid >> 3);
+}
+
+}  // namespace mpck

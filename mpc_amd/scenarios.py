@@ -1,0 +1,158 @@
+"""Seeded synthetic scenario family of the benchmark.
+
+A scenario = one MPC tick on a platform that moves as ``A sin(w t + phi)`` (the motion driven by
+the reference's tests/simulate_platform_motion.py:17,23,42-43,59: f = 0.1 Hz, A = 0.2 m on the
+prismatic x axis or 20 deg about z), the arm near one of the two SRDF start poses
+(mpc_moveit_config/config/mpc.srdf:16-31) and a goal pose near the current tip pose.
+
+All kinematics (tip pose, Jacobian, platform prediction) come from a ``kin`` backend with
+``fk(q)->[N,6]``, ``jacobian(q)->[N,6,6]``, ``predict_base_dynamic(base)->[N,H,12]`` returning numpy
+arrays: the product passes :class:`DeviceKinematics` (libmpc_amd), tests may pass the CPU oracle.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Optional
+
+import numpy as np
+
+from .params import MpcParams
+
+# SRDF group states in joint order pan, lift, elbow, wrist1, wrist2, wrist3
+Q_LINEAR_READY = np.array([5.1508, -0.7884, -2.2445, -0.9465, 1.2523, 3.4515])
+Q_ANGULAR_READY = np.array([4.9015, -1.3217, -2.0265, -0.5868, 1.4311, 3.2573])
+ARM_OFFSET = np.array([0.0, 0.1, 0.5])       # base_joint origin, mpc_robot.xacro:17-22
+PLATFORM_FREQ_HZ = 0.1                        # simulate_platform_motion.py:42
+BASE_SEED = 20250614
+
+
+@dataclass
+class HostScenarios:
+    """numpy (host) copy of a scenario batch, rows [N][...]."""
+
+    motion: str
+    q0: np.ndarray          # [N,6]
+    base: np.ndarray        # [N,12] platform state [P, Theta, V, Omega]
+    state0: np.ndarray      # [N,18]
+    target: np.ndarray      # [N,6]
+    base_traj: np.ndarray   # [N,H,12]
+    Jc: np.ndarray          # [N,36]
+    x: np.ndarray           # [N,6H] evaluation point / SLSQP start
+    u_init: np.ndarray      # [N,6]  DLS guess (ur_mpc.py:173-175)
+    u_prev: Optional[np.ndarray]    # [N,6] or None
+    has_prev: Optional[np.ndarray]  # [N] uint8 or None
+    active: np.ndarray      # [N] bool: False where compute_control exits early (ur_mpc.py:108)
+
+    @property
+    def count(self):
+        return self.q0.shape[0]
+
+    def as_oracle_dict(self, lo=0, hi=None):
+        sl = slice(lo, hi)
+        return dict(x=self.x[sl], state0=self.state0[sl], target=self.target[sl], base_traj=self.base_traj[sl],
+                    Jc=self.Jc[sl], u_prev=None if self.u_prev is None else self.u_prev[sl],
+                    has_prev=None if self.has_prev is None else self.has_prev[sl])
+
+
+def world_to_base(v: np.ndarray, yaw: np.ndarray) -> np.ndarray:
+    """Batched ur_mpc.py:714-720."""
+    c, s = np.cos(yaw), np.sin(yaw)
+    out = np.empty_like(v)
+    out[:, 0] = c * v[:, 0] + s * v[:, 1]
+    out[:, 1] = -s * v[:, 0] + c * v[:, 1]
+    out[:, 2] = v[:, 2]
+    return out
+
+
+def dls_guess(Jc: np.ndarray, base: np.ndarray, ee_pos: np.ndarray) -> np.ndarray:
+    """Batched damped-least-squares start of compute_control (ur_mpc.py:112-143,168-175)."""
+    P, Th, V, Om = base[:, 0:3], base[:, 3:6], base[:, 6:9], base[:, 9:12]
+    v_ind = V + np.cross(Om, ee_pos - P)
+    tl = world_to_base(-v_ind, Th[:, 2])
+    ta = world_to_base(-Om, Th[:, 2])
+    twist = np.concatenate([tl, ta], axis=1)
+    J = Jc.reshape(-1, 6, 6)
+    JJt = J @ np.transpose(J, (0, 2, 1)) + 0.01 * np.eye(6)
+    y = np.linalg.solve(JJt, twist[:, :, None])
+    return (np.transpose(J, (0, 2, 1)) @ y)[:, :, 0]
+
+
+def make_scenarios(params: MpcParams, kin, count: int, motion: str = "linear", cfg_id: int = 2,
+                   with_prev: bool = False, goal_jitter: float = 0.05, first: int = 0) -> HostScenarios:
+    """Scenarios ``first .. first+count-1`` of configuration ``cfg_id``.  Row i depends only on
+    (cfg_id, i), so a shard [first, first+count) equals the same rows of the full batch."""
+    if motion not in ("linear", "angular"):
+        raise ValueError("motion must be 'linear' or 'angular'")
+    H = params.horizon
+    K = 14 + 6 * H
+    rng = np.random.default_rng(BASE_SEED + cfg_id)
+    if first:
+        # Generator.uniform draws one double per value: skip the rows of earlier shards
+        rng.bit_generator.advance(first * K)
+    U = rng.random((count, K))
+    q0 = (Q_LINEAR_READY if motion == "linear" else Q_ANGULAR_READY) + (U[:, 0:6] * 0.2 - 0.1)
+    w = 2.0 * np.pi * PLATFORM_FREQ_HZ
+    phi = U[:, 7] * 2.0 * np.pi
+    base = np.zeros((count, 12))
+    if motion == "linear":
+        A = 0.05 + U[:, 6] * 0.25
+        base[:, 0] = A * np.sin(phi)
+        base[:, 6] = A * w * np.cos(phi)
+    else:
+        A = np.radians(5.0 + U[:, 6] * 25.0)
+        base[:, 5] = A * np.sin(phi)
+        base[:, 11] = A * w * np.cos(phi)
+    pose = np.asarray(kin.fk(q0))                          # tip in base_link
+    yaw = base[:, 5]
+    local = ARM_OFFSET + pose[:, 0:3]
+    c, s = np.cos(yaw), np.sin(yaw)
+    p0 = np.stack([base[:, 0] + c * local[:, 0] - s * local[:, 1],
+                   base[:, 1] + s * local[:, 0] + c * local[:, 1],
+                   base[:, 2] + local[:, 2]], axis=1)
+    o0 = pose[:, 3:6].copy()
+    o0[:, 2] += yaw
+    state0 = np.concatenate([q0, np.zeros((count, 6)), p0, o0], axis=1)   # dq0 = 0 (mpc_action_server.py:83)
+    target = np.concatenate([p0, o0], axis=1) + (U[:, 8:14] * 2.0 - 1.0) * goal_jitter
+    base_traj = np.asarray(kin.predict_base_dynamic(base))
+    Jc = np.asarray(kin.jacobian(q0)).reshape(count, 36)
+    u_init = dls_guess(Jc, base, p0)
+    x = np.tile(u_init, (1, H)) + (U[:, 14:] * 0.1 - 0.05)
+    lim = np.tile(np.asarray(params.v_lim), H)
+    x = np.clip(x, -lim, lim)
+    active = ~((np.linalg.norm(base[:, 6:9], axis=1) < 0.01) & (np.linalg.norm(base[:, 9:12], axis=1) < 0.01))
+    u_prev = x[:, :6].copy() if with_prev else None
+    has_prev = np.ones(count, dtype=np.uint8) if with_prev else None
+    return HostScenarios(motion, q0, base, state0, target, base_traj, Jc, np.ascontiguousarray(x), u_init,
+                         u_prev, has_prev, active)
+
+
+class DeviceKinematics:
+    """``kin`` backend running on the GPU through libmpc_amd (MpcContext)."""
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+
+    def _up(self, a):
+        import torch
+
+        return torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float64).to(self.ctx.device)
+
+    def fk(self, q):
+        return self.ctx.fk(self._up(q)).cpu().numpy()
+
+    def jacobian(self, q):
+        return self.ctx.jacobian(self._up(q)).cpu().numpy()
+
+    def predict_base_dynamic(self, base):
+        return self.ctx.predict_base_dynamic(self._up(base)).cpu().numpy()
+
+
+def to_device(ctx, hs: HostScenarios):
+    """Upload a host batch: returns (ScenarioBatch, x tensor)."""
+    import torch
+
+    from .batch import ScenarioBatch
+
+    sc = ScenarioBatch.from_numpy(ctx.device, hs.state0, hs.target, hs.base_traj, hs.Jc, hs.u_prev, hs.has_prev)
+    x = torch.as_tensor(hs.x, dtype=torch.float64).to(ctx.device)
+    return sc, x

@@ -1,0 +1,172 @@
+"""TEST INFRASTRUCTURE — generates tests/golden/*.npz by running the REAL reference
+(/root/reference, imported under ROS stubs by oracle/ref_shim.py) in this container.
+
+    python -m oracle.gen_golden
+
+The fixtures hold data only (inputs and the reference's outputs); no reference source.  The
+Jacobian provider injected into the reference is this repo's own (oracle.numpy_ref.ur20_jacobian),
+because MoveIt is not part of the reference tree — "parity unpinned" at that boundary.
+
+Scenario inputs come from mpc_amd.scenarios.make_scenarios driven by the C oracle's kinematics,
+i.e. the same seeded family bench.py uses.
+"""
+from __future__ import annotations
+
+import contextlib
+import io
+import os
+import sys
+import time
+
+import numpy as np
+from scipy.optimize._numdiff import approx_derivative
+
+from mpc_amd.params import MpcParams
+from mpc_amd.scenarios import make_scenarios
+from oracle import ref_shim
+from oracle.numpy_ref import base_traj_from_array
+from oracle.oracle import COracle, OracleKinematics, ref_params_from
+
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+
+
+def _ref_for(H):
+    return ref_shim.load_reference({"mpc_controller/horizon": H})
+
+
+def eval_cases():
+    """f, c, scipy FD grad and dc/dx of the reference at seeded points."""
+    cases = []
+    for H, motions, n_per, store_jac in ((1, ("linear", "angular"), 3, True), (3, ("linear", "angular"), 3, True),
+                                          (20, ("linear", "angular"), 2, True), (100, ("linear",), 1, False)):
+        mp = MpcParams.reference_yaml_defaults(horizon=H)
+        kin = OracleKinematics(COracle(ref_params_from(mp)))
+        for motion in motions:
+            for with_prev in (False, True):
+                hs = make_scenarios(mp, kin, n_per, motion=motion, cfg_id=100 + H, with_prev=with_prev)
+                for i in range(n_per):
+                    x = hs.x[i].copy()
+                    if i == 1:  # put some variables on / within eps of the upper bound: FD sign flip
+                        lim = np.tile(np.asarray(mp.v_lim), H)
+                        x[0] = lim[0]
+                        x[min(7, 6 * H - 1)] = lim[min(7, 6 * H - 1)] - 5e-4
+                        x[6 * H - 1] = -lim[6 * H - 1]
+                    ref = _ref_for(H)
+                    ref._J_cached = np.array(hs.Jc[i].reshape(6, 6))
+                    if with_prev:
+                        ref.previous_control = hs.u_prev[i].copy()
+                    state0 = hs.state0[i].copy()
+                    target = {"position": hs.target[i, :3].copy(), "orientation": hs.target[i, 3:].copy()}
+                    bt = base_traj_from_array(hs.base_traj[i])
+                    fun = lambda z: ref._cost_function(z, state0, target, bt)
+                    con = ref._get_constraints(state0, bt)[0]["fun"]
+                    bnds = ref._get_bounds(x)
+                    lb = np.array([b[0] for b in bnds]); ub = np.array([b[1] for b in bnds])
+                    t0 = time.time()
+                    f0 = fun(x); c0 = con(x)
+                    g = approx_derivative(fun, x, method="2-point", abs_step=1e-3, f0=f0, bounds=(lb, ub))
+                    a = approx_derivative(con, x, method="2-point", abs_step=1e-3, f0=c0, bounds=(lb, ub)) \
+                        if store_jac else None
+                    print(f"H={H} {motion} prev={with_prev} i={i}: f={f0:.6f} ({time.time()-t0:.1f}s)", flush=True)
+                    cases.append(dict(H=H, motion=motion, with_prev=with_prev, x=x, state0=state0,
+                                      target=hs.target[i].copy(), base_traj=hs.base_traj[i].copy(),
+                                      Jc=hs.Jc[i].copy(),
+                                      u_prev=hs.u_prev[i].copy() if with_prev else np.zeros(6),
+                                      f=f0, c=c0, grad=np.atleast_1d(g), jac=a))
+    return cases
+
+
+def save_eval(cases):
+    byH = {}
+    for c in cases:
+        byH.setdefault(c["H"], []).append(c)
+    for H, cs in byH.items():
+        arrs = dict(
+            H=np.int64(H), motion=np.array([c["motion"] for c in cs]),
+            with_prev=np.array([c["with_prev"] for c in cs], dtype=np.uint8),
+            x=np.stack([c["x"] for c in cs]), state0=np.stack([c["state0"] for c in cs]),
+            target=np.stack([c["target"] for c in cs]), base_traj=np.stack([c["base_traj"] for c in cs]),
+            Jc=np.stack([c["Jc"] for c in cs]), u_prev=np.stack([c["u_prev"] for c in cs]),
+            f=np.array([c["f"] for c in cs]), c=np.stack([c["c"] for c in cs]),
+            grad=np.stack([c["grad"] for c in cs]))
+        if cs[0]["jac"] is not None:
+            arrs["jac"] = np.stack([c["jac"] for c in cs])  # [case][m][n] as scipy returns it
+        np.savez_compressed(os.path.join(OUT, f"eval_H{H}.npz"), **arrs)
+
+
+def solve_cases():
+    """Full compute_control ticks of the reference (real scipy SLSQP)."""
+    out = []
+    for H, motion, n_s in ((1, "linear", 3), (1, "angular", 2), (3, "linear", 2), (3, "angular", 2), (20, "linear", 1)):
+        mp = MpcParams.reference_yaml_defaults(horizon=H)
+        kin = OracleKinematics(COracle(ref_params_from(mp)))
+        hs = make_scenarios(mp, kin, n_s, motion=motion, cfg_id=200 + H, goal_jitter=0.0)
+        for i in range(n_s):
+            ref = _ref_for(H)
+            js = {"position": hs.q0[i].copy(), "velocity": np.zeros(6)}
+            ee = {"position": hs.state0[i, 12:15].copy(), "orientation": hs.state0[i, 15:18].copy()}
+            tg = {"position": hs.target[i, :3].copy(), "orientation": hs.target[i, 3:].copy()}
+            b = hs.base[i]
+            bs = {"position": b[0:3].copy(), "orientation": b[3:6].copy(), "linear_velocity": b[6:9].copy(),
+                  "angular_velocity": b[9:12].copy()}
+            controls = []
+            sols = []
+            t0 = time.time()
+            for tick in range(2):  # second tick exercises warm start + previous_control
+                with contextlib.redirect_stdout(io.StringIO()):
+                    u = ref.compute_control(js, ee, tg, bs)
+                controls.append(np.array(u))
+                sols.append(np.array(ref.previous_solution) if ref.previous_solution is not None
+                            else np.full(6 * H, np.nan))
+            print(f"solve H={H} {motion} i={i}: u0={controls[0][:3]} ({time.time()-t0:.1f}s)", flush=True)
+            out.append(dict(H=H, motion=motion, q0=hs.q0[i], ee=hs.state0[i, 12:18], target=hs.target[i],
+                            base=b, control=np.stack(controls), solution=np.stack(sols)))
+    return out
+
+
+def save_solve(cases):
+    byH = {}
+    for c in cases:
+        byH.setdefault(c["H"], []).append(c)
+    for H, cs in byH.items():
+        np.savez_compressed(
+            os.path.join(OUT, f"solve_H{H}.npz"), H=np.int64(H), motion=np.array([c["motion"] for c in cs]),
+            q0=np.stack([c["q0"] for c in cs]), ee=np.stack([c["ee"] for c in cs]),
+            target=np.stack([c["target"] for c in cs]), base=np.stack([c["base"] for c in cs]),
+            control=np.stack([c["control"] for c in cs]), solution=np.stack([c["solution"] for c in cs]))
+
+
+def base_motion_cases():
+    """predict_base_motion of the reference: dynamic model and 3 ticks of the stateful kinematic one."""
+    rng = np.random.default_rng(77)
+    H = 5
+    states = []
+    for t in range(3):
+        states.append(dict(position=rng.uniform(-.3, .3, 3), orientation=np.array([0, 0, rng.uniform(-.4, .4)]),
+                           linear_velocity=rng.uniform(-.2, .2, 3), angular_velocity=rng.uniform(-.1, .1, 3)))
+    dyn = _ref_for(H)
+    dyn_out = [np.array([np.concatenate([e["position"], e["orientation"], e["linear_velocity"],
+                                         e["angular_velocity"]]) for e in dyn.predict_base_motion(s, H)])
+               for s in states]
+    kinm = ref_shim.load_reference({"mpc_controller/horizon": H,
+                                    "mpc_controller/base_dynamics/use_dynamic_model": False})
+    kin_out = [np.array([np.concatenate([e["position"], e["orientation"], e["linear_velocity"],
+                                         e["angular_velocity"]]) for e in kinm.predict_base_motion(s, H)])
+               for s in states]
+    base_in = np.array([np.concatenate([s["position"], s["orientation"], s["linear_velocity"],
+                                        s["angular_velocity"]]) for s in states])
+    np.savez_compressed(os.path.join(OUT, "base_motion.npz"), H=np.int64(H), base=base_in,
+                        dynamic=np.stack(dyn_out), kinematic=np.stack(kin_out))
+
+
+def main():
+    if not ref_shim.reference_available():
+        sys.exit("reference tree not present: fixtures can only be generated where /root/reference exists")
+    os.makedirs(OUT, exist_ok=True)
+    base_motion_cases()
+    save_eval(eval_cases())
+    save_solve(solve_cases())
+
+
+if __name__ == "__main__":
+    main()

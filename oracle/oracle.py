@@ -161,3 +161,32 @@ class COracle:
         for i in range(base12.shape[0]):
             lib().orc_predict_base_dynamic(_dp(base12[i]), _dp(dyn), p.dt, self.H, _dp(out[i]))
         return out
+
+
+class OracleKinematics:
+    """``kin`` backend for mpc_amd.scenarios.make_scenarios backed by the C oracle (tests only)."""
+
+    def __init__(self, co: COracle):
+        self.co = co
+
+    def fk(self, q):
+        pos, rpy = self.co.fk(q)
+        return np.concatenate([pos, rpy], axis=1)
+
+    def jacobian(self, q):
+        return self.co.jacobian(q)
+
+    def predict_base_dynamic(self, base):
+        return self.co.predict_base_dynamic(base)
+
+
+def ref_params_from(mp) -> RefParams:
+    """RefParams (oracle) with the values of an mpc_amd MpcParams (duck-typed, tests only)."""
+    kin = KinTable(a=tuple(mp.kin.a), d=tuple(mp.kin.d), ca=tuple(mp.kin.ca), sa=tuple(mp.kin.sa),
+                   base_c=mp.kin.base_c, base_s=mp.kin.base_s, tool=tuple(mp.kin.tool))
+    return RefParams(horizon=mp.horizon, dt=mp.dt, dyn_dt=mp.dyn_dt, w_position=mp.w_position,
+                     w_orientation=mp.w_orientation, w_control=mp.w_control, w_smooth=mp.w_smooth,
+                     w_damping=mp.w_damping, w_linear=mp.w_linear, w_angular=mp.w_angular,
+                     use_dynamic_model=mp.use_dynamic_model, base_mass=mp.base_mass, base_Iz=mp.base_Iz,
+                     k_v=mp.k_v, k_omega=mp.k_omega, tau_linear=mp.tau_linear, tau_angular=mp.tau_angular,
+                     fd_eps=mp.fd_eps, ftol=mp.ftol, maxiter=mp.maxiter, kin=kin)

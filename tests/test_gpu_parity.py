@@ -1,0 +1,165 @@
+"""GPU: the HIP path (through the C-ABI) against the CPU oracle and the reference's golden vectors."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import assert_cost_close, assert_grad_close, host_scenarios, params_for
+from mpc_amd import _ffi
+from mpc_amd.batch import MpcContext
+from mpc_amd.scenarios import DeviceKinematics, make_scenarios, to_device
+
+pytestmark = pytest.mark.gpu
+
+ALGOS = [_ffi.ALGO_ROLLOUT, _ffi.ALGO_PREFIX]
+
+
+def _ctx(mp, N):
+    if not torch.cuda.is_available():
+        pytest.fail("no GPU visible: the gpu-marked tests need a real MI355X")
+    return MpcContext(mp, max_scenarios=N, device=0)
+
+
+def _supported(mp):
+    try:
+        ctx = MpcContext(mp, 1, 0)
+        ctx.close()
+        return True
+    except _ffi.MpcError as e:
+        if e.code == -3:
+            return False
+        raise
+
+
+def _compare(res, cost, grad, con, jac, tight_con=True):
+    assert_cost_close(res.cost.cpu().numpy(), cost)
+    assert_grad_close(res.grad.cpu().numpy(), grad)
+    np.testing.assert_allclose(res.con.cpu().numpy(), con, rtol=1e-13, atol=1e-13)
+    if jac is not None:
+        # entries are +-dt-sized FD quotients of joint sums; everything else is exactly zero
+        got = res.con_jac.cpu().numpy()
+        np.testing.assert_allclose(got, jac, rtol=1e-9, atol=1e-10)
+        assert np.array_equal(got == 0.0, jac == 0.0)
+
+
+@pytest.mark.parametrize("algo", ALGOS)
+@pytest.mark.parametrize("H,motion,prev", [(1, "linear", False), (1, "angular", True), (3, "linear", True),
+                                            (3, "angular", False), (20, "linear", False), (20, "angular", True)])
+def test_eval_fd_matches_oracle(algo, H, motion, prev):
+    mp = params_for(H, algo=algo)
+    if not _supported(mp):
+        pytest.skip("algo not available for these parameters")
+    N = 96
+    co, hs = host_scenarios(mp, N, motion=motion, cfg_id=11, with_prev=prev, near_bounds=True)
+    cost, grad, con, jac = co.eval_fd(hs.as_oracle_dict())
+    ctx = _ctx(mp, N)
+    sc, x = to_device(ctx, hs)
+    res = ctx.eval_fd(sc, x)
+    torch.cuda.synchronize()
+    _compare(res, cost, grad, con, jac)
+    # f and c only (SLSQP mode 1) agree with the fd call's f and c bit for bit
+    res1 = ctx.eval(sc, x)
+    c1, con1 = co.eval(hs.as_oracle_dict())
+    assert_cost_close(res1.cost.cpu().numpy(), c1)
+    np.testing.assert_allclose(res1.con.cpu().numpy(), con1, rtol=1e-13, atol=1e-13)
+
+
+@pytest.mark.parametrize("algo", ALGOS)
+def test_long_horizon_h100(algo):
+    mp = params_for(100, algo=algo)
+    if not _supported(mp):
+        pytest.skip("algo not available for these parameters")
+    N = 6
+    co, hs = host_scenarios(mp, N, motion="linear", cfg_id=4, with_prev=True, near_bounds=True)
+    cost, grad, con, jac = co.eval_fd(hs.as_oracle_dict())
+    ctx = _ctx(mp, N)
+    sc, x = to_device(ctx, hs)
+    res = ctx.eval_fd(sc, x)
+    torch.cuda.synchronize()
+    _compare(res, cost, grad, con, jac)
+
+
+@pytest.mark.parametrize("algo", ALGOS)
+@pytest.mark.parametrize("H", [1, 3, 20, 100])
+def test_against_reference_golden(golden_dir, algo, H):
+    path = os.path.join(golden_dir, f"eval_H{H}.npz")
+    if not os.path.exists(path):
+        pytest.skip("golden not generated")
+    g = np.load(path, allow_pickle=False)
+    mp = params_for(H, algo=algo)
+    if not _supported(mp):
+        pytest.skip("algo not available for these parameters")
+    N = g["x"].shape[0]
+    ctx = _ctx(mp, N)
+    from mpc_amd.batch import ScenarioBatch
+
+    sc = ScenarioBatch.from_numpy(ctx.device, g["state0"], g["target"], g["base_traj"], g["Jc"], g["u_prev"],
+                                  g["with_prev"])
+    x = torch.as_tensor(g["x"], dtype=torch.float64).to(ctx.device)
+    res = ctx.eval_fd(sc, x)
+    torch.cuda.synchronize()
+    jac = np.transpose(g["jac"], (0, 2, 1)) if "jac" in g.files else None
+    _compare(res, g["f"], g["grad"], g["c"], jac)
+
+
+def test_device_kinematics_match_oracle():
+    mp = params_for(20)
+    co, hs = host_scenarios(mp, 64, motion="angular", cfg_id=12)
+    ctx = _ctx(mp, 64)
+    q = torch.as_tensor(hs.q0).to(ctx.device)
+    np.testing.assert_allclose(ctx.jacobian(q).cpu().numpy(), co.jacobian(hs.q0), rtol=0, atol=1e-14)
+    pos, rpy = co.fk(hs.q0)
+    pose = ctx.fk(q).cpu().numpy()
+    np.testing.assert_allclose(pose[:, :3], pos, rtol=0, atol=1e-14)
+    np.testing.assert_allclose(pose[:, 3:], rpy, rtol=0, atol=1e-13)
+    bt = ctx.predict_base_dynamic(torch.as_tensor(hs.base).to(ctx.device)).cpu().numpy()
+    np.testing.assert_allclose(bt, co.predict_base_dynamic(hs.base), rtol=1e-14, atol=1e-15)
+    # the whole scenario family built on the device equals the one built with the oracle
+    hd = make_scenarios(mp, DeviceKinematics(ctx), 64, motion="angular", cfg_id=12)
+    np.testing.assert_allclose(hd.state0, hs.state0, rtol=0, atol=1e-13)
+    np.testing.assert_allclose(hd.x, hs.x, rtol=0, atol=1e-11)
+
+
+def test_algos_agree_at_scale():
+    """Size-independent property at the benchmark's shape: the two kernels agree with each other on
+    4,096 scenarios (the oracle checks a strided sample of the same batch)."""
+    N = 4096
+    mp1 = params_for(20, algo=_ffi.ALGO_ROLLOUT)
+    co, hs = host_scenarios(mp1, N, motion="linear", cfg_id=2)
+    ctx1 = _ctx(mp1, N)
+    sc, x = to_device(ctx1, hs)
+    r1 = ctx1.eval_fd(sc, x)
+    torch.cuda.synchronize()
+    idx = np.arange(0, N, 64)
+    sub = {k: (None if v is None else v[idx]) for k, v in hs.as_oracle_dict().items()}
+    cost, grad, con, jac = co.eval_fd(sub)
+    assert_cost_close(r1.cost.cpu().numpy()[idx], cost)
+    assert_grad_close(r1.grad.cpu().numpy()[idx], grad)
+    mp2 = params_for(20, algo=_ffi.ALGO_PREFIX)
+    if not _supported(mp2):
+        pytest.skip("prefix kernel not available")
+    ctx2 = _ctx(mp2, N)
+    r2 = ctx2.eval_fd(sc, x)
+    torch.cuda.synchronize()
+    assert_cost_close(r2.cost.cpu().numpy(), r1.cost.cpu().numpy())
+    assert_grad_close(r2.grad.cpu().numpy(), r1.grad.cpu().numpy())
+    np.testing.assert_allclose(r2.con_jac.cpu().numpy(), r1.con_jac.cpu().numpy(), rtol=1e-9, atol=1e-10)
+
+
+def test_empty_batch_and_bad_arguments():
+    mp = params_for(3)
+    ctx = _ctx(mp, 8)
+    co, hs = host_scenarios(mp, 4)
+    sc, x = to_device(ctx, hs)
+    res = ctx.eval_fd(sc.slice(0, 0), x[0:0])          # empty batch is a no-op
+    assert res.cost.numel() == 0
+    with pytest.raises(ValueError):
+        ctx.eval_fd(sc, x[:, :-1].contiguous())        # wrong n
+    with pytest.raises(ValueError):
+        ctx.eval_fd(sc, x.float())                     # wrong dtype
+    with pytest.raises(ValueError):
+        ctx.eval_fd(sc, x.cpu())                       # host tensor
+    big, xb = to_device(ctx, host_scenarios(mp, 9)[1])
+    with pytest.raises(ValueError):
+        ctx.eval_fd(big, xb)                           # more scenarios than the context was sized for

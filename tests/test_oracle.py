@@ -1,0 +1,138 @@
+"""CPU: the oracle is pinned — C port vs numpy restatement vs the real reference / its golden vectors."""
+import os
+
+import numpy as np
+import pytest
+
+from helpers import assert_cost_close, assert_grad_close, host_scenarios, params_for
+from oracle import ref_shim
+from oracle.numpy_ref import NumpyRefMPC, RefParams, base_traj_from_array, base_traj_to_array, ur20_fk, ur20_jacobian
+from oracle.oracle import COracle, OrcParams, lib, ref_params_from
+
+
+def _golden(golden_dir, name):
+    path = os.path.join(golden_dir, name)
+    if not os.path.exists(path):
+        pytest.skip(f"{name} not generated")
+    return np.load(path, allow_pickle=False)
+
+
+@pytest.mark.parametrize("H", [1, 3, 20, 100])
+def test_c_oracle_matches_reference_golden(golden_dir, H):
+    g = _golden(golden_dir, f"eval_H{H}.npz")
+    mp = params_for(H)
+    co = COracle(ref_params_from(mp))
+    sc = dict(x=g["x"], state0=g["state0"], target=g["target"], base_traj=g["base_traj"], Jc=g["Jc"],
+              u_prev=g["u_prev"], has_prev=g["with_prev"])
+    cost, grad, con, jac = co.eval_fd(sc, want_jac="jac" in g.files)
+    assert_cost_close(cost, g["f"])
+    np.testing.assert_array_equal(con, g["c"])           # joint sums are sequential in both: bit-exact
+    assert_grad_close(grad, g["grad"])
+    if "jac" in g.files:
+        np.testing.assert_array_equal(np.transpose(jac, (0, 2, 1)), g["jac"])
+    c2, con2 = co.eval(sc)
+    np.testing.assert_array_equal(c2, cost)
+    np.testing.assert_array_equal(con2, con)
+
+
+@pytest.mark.parametrize("H", [1, 3])
+def test_numpy_restatement_matches_reference_golden(golden_dir, H):
+    g = _golden(golden_dir, f"eval_H{H}.npz")
+    for i in range(g["x"].shape[0]):
+        ref = NumpyRefMPC(RefParams(horizon=H))
+        ref.J_cached = g["Jc"][i].reshape(6, 6)
+        if g["with_prev"][i]:
+            ref.previous_control = g["u_prev"][i]
+        tgt = {"position": g["target"][i, :3], "orientation": g["target"][i, 3:]}
+        bt = base_traj_from_array(g["base_traj"][i])
+        f, c, gr, a = ref.fd_eval(g["x"][i], g["state0"][i], tgt, bt, fast_constraint=False)
+        assert f == g["f"][i]                              # same numpy calls -> bit-identical
+        np.testing.assert_array_equal(c, g["c"][i])
+        np.testing.assert_array_equal(gr, g["grad"][i])
+        np.testing.assert_array_equal(a, g["jac"][i])
+
+
+@pytest.mark.skipif(not ref_shim.reference_available(), reason="reference tree not on this box")
+@pytest.mark.parametrize("H,motion,prev", [(1, "linear", False), (3, "angular", True), (20, "linear", True)])
+def test_numpy_restatement_matches_live_reference(H, motion, prev):
+    mp = params_for(H)
+    _, hs = host_scenarios(mp, 2, motion=motion, cfg_id=31, with_prev=prev)
+    for i in range(2):
+        ref = ref_shim.load_reference({"mpc_controller/horizon": H})
+        mine = NumpyRefMPC(RefParams(horizon=H))
+        ref._J_cached = hs.Jc[i].reshape(6, 6).copy()
+        mine.J_cached = hs.Jc[i].reshape(6, 6).copy()
+        if prev:
+            ref.previous_control = hs.u_prev[i].copy()
+            mine.previous_control = hs.u_prev[i].copy()
+        tgt = {"position": hs.target[i, :3], "orientation": hs.target[i, 3:]}
+        bt = base_traj_from_array(hs.base_traj[i])
+        assert ref._cost_function(hs.x[i], hs.state0[i], tgt, bt) == mine.cost_function(hs.x[i], hs.state0[i], tgt, bt)
+        np.testing.assert_array_equal(ref._get_constraints(hs.state0[i], bt)[0]["fun"](hs.x[i]),
+                                      mine.constraint(hs.x[i], hs.state0[i]))
+        assert ref._get_bounds(hs.x[i]) == mine.bounds()
+        b = hs.base[i]
+        bs = {"position": b[0:3], "orientation": b[3:6], "linear_velocity": b[6:9], "angular_velocity": b[9:12]}
+        got = base_traj_to_array(mine.predict_base_motion(bs, H))
+        want = base_traj_to_array(ref.predict_base_motion(bs, H))
+        np.testing.assert_array_equal(got, want)
+
+
+def test_base_motion_golden(golden_dir):
+    g = _golden(golden_dir, "base_motion.npz")
+    H = int(g["H"])
+    co = COracle(RefParams(horizon=H))
+    np.testing.assert_array_equal(co.predict_base_dynamic(g["base"]), g["dynamic"])
+    npref = NumpyRefMPC(RefParams(horizon=H, use_dynamic_model=False))
+    for t in range(g["base"].shape[0]):   # stateful filters: ticks in order
+        b = g["base"][t]
+        bs = {"position": b[0:3], "orientation": b[3:6], "linear_velocity": b[6:9], "angular_velocity": b[9:12]}
+        np.testing.assert_array_equal(base_traj_to_array(npref.predict_base_motion(bs, H)), g["kinematic"][t])
+
+
+def test_jacobian_is_derivative_of_fk():
+    """The Jacobian provider (this repo's own, unpinned vs MoveIt) is at least self-consistent."""
+    rng = np.random.default_rng(5)
+    co = COracle(RefParams(horizon=1))
+    for _ in range(5):
+        q = rng.uniform(-3, 3, 6)
+        J = co.jacobian(q)[0]
+        np.testing.assert_array_equal(J, ur20_jacobian(q))
+        p0, _ = ur20_fk(q)
+        for j in range(6):
+            dq = np.zeros(6); dq[j] = 1e-6
+            pp, _ = ur20_fk(q + dq); pm, _ = ur20_fk(q - dq)
+            np.testing.assert_allclose((pp - pm) / 2e-6, J[:3, j], atol=1e-8)
+        # angular columns are unit joint axes; shoulder axis is the base z axis
+        np.testing.assert_allclose(np.linalg.norm(J[3:, :], axis=0), 1.0, atol=1e-14)
+        np.testing.assert_array_equal(J[3:, 0], [0.0, 0.0, 1.0])
+
+
+def test_fd_step_rule_matches_scipy():
+    from scipy.optimize._numdiff import _adjust_scheme_to_bounds
+
+    rng = np.random.default_rng(3)
+    lb, ub = -2.0, 2.0
+    xs = np.concatenate([rng.uniform(lb, ub, 50), [ub, lb, ub - 5e-4, ub - 1e-3, ub - 1.0000001e-3, 0.0]])
+    h, _ = _adjust_scheme_to_bounds(xs, np.full_like(xs, 1e-3), 1, "1-sided", np.full_like(xs, lb), np.full_like(xs, ub))
+    got = np.array([lib().orc_fd_step(float(v), lb, ub, 1e-3) for v in xs])
+    np.testing.assert_array_equal(got, h)
+    # bounds narrower than the step: scipy shrinks the step to the larger side
+    h2, _ = _adjust_scheme_to_bounds(np.array([0.0002]), np.array([1e-3]), 1, "1-sided", np.array([0.0]), np.array([0.0005]))
+    assert lib().orc_fd_step(0.0002, 0.0, 0.0005, 1e-3) == h2[0]
+
+
+def test_c_oracle_vs_numpy_random():
+    mp = params_for(3)
+    co, hs = host_scenarios(mp, 4, motion="angular", cfg_id=9, with_prev=True, near_bounds=True)
+    cost, grad, con, jac = co.eval_fd(hs.as_oracle_dict())
+    for i in range(4):
+        ref = NumpyRefMPC(ref_params_from(mp))
+        ref.J_cached = hs.Jc[i].reshape(6, 6)
+        ref.previous_control = hs.u_prev[i]
+        tgt = {"position": hs.target[i, :3], "orientation": hs.target[i, 3:]}
+        f, c, g, a = ref.fd_eval(hs.x[i], hs.state0[i], tgt, base_traj_from_array(hs.base_traj[i]))
+        assert_cost_close(cost[i], f)
+        np.testing.assert_array_equal(con[i], c)
+        assert_grad_close(grad[i], g)
+        np.testing.assert_array_equal(jac[i].T, a)
