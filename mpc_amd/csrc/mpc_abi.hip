@@ -156,8 +156,8 @@ int mpc_eval(mpc_ctx *ctx, const mpc_scenarios *sc, const double *x, double *cos
     if (rc) return rc;
     rc = check_scenarios(ctx, sc, x);
     if (rc) return rc;
-    if (!cost) return fail(ctx, MPC_ERR_INVALID_ARG, "cost is NULL");
     if (sc->count == 0) return MPC_OK;
+    if (!cost) return fail(ctx, MPC_ERR_INVALID_ARG, "cost is NULL");
     MPC_HIP(ctx, hipSetDevice(ctx->device));
     MPC_HIP(ctx, mpck::launch_rollout(ctx->params, ctx->d_decay, *sc, x, cost, 1, con, nullptr, 0,
                                       static_cast<hipStream_t>(stream)));
@@ -171,8 +171,8 @@ int mpc_eval_fd(mpc_ctx *ctx, const mpc_scenarios *sc, const double *x, double *
     if (rc) return rc;
     rc = check_scenarios(ctx, sc, x);
     if (rc) return rc;
-    if (!cost) return fail(ctx, MPC_ERR_INVALID_ARG, "cost is NULL");
     if (sc->count == 0) return MPC_OK;
+    if (!cost) return fail(ctx, MPC_ERR_INVALID_ARG, "cost is NULL");
     hipStream_t st = static_cast<hipStream_t>(stream);
     MPC_HIP(ctx, hipSetDevice(ctx->device));
     if (resolve_algo(ctx) == MPC_ALGO_PREFIX) {
