@@ -1,0 +1,213 @@
+#!/usr/bin/env python3
+"""Benchmark of the MPC inner loop on MI355X: objective + constraint + FD-gradient evals/s.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--scenarios S] [--horizon H]
+
+A "step" = one mpc_eval_fd pass over the batch resident in HBM: for every scenario f, c, the
+forward-difference gradient and the dense forward-difference constraint Jacobian (what scipy's
+SLSQP requests per major iteration from the reference's callables, ur_mpc.py:188-200).  Default
+workload: 65,536 linear-platform-motion scenarios per GPU at H=20 (the size BASELINE.json's
+north_star quotes its target on; configs[1]'s 4,096-scenario rate is reported alongside).  For
+N > 1 the driver launches one rank per GPU (torch.distributed, backend nccl = RCCL); scenarios are
+sharded contiguously, nothing is exchanged per step, one RCCL all_gather of the per-scenario costs
+closes the run (weak scaling).  Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from mpc_amd import _ffi  # noqa: E402
+from mpc_amd.batch import EvalResult, MpcContext  # noqa: E402
+from mpc_amd.params import MpcParams  # noqa: E402
+from mpc_amd.scenarios import DeviceKinematics, make_scenarios, to_device  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+FP64_VALU_PEAK_TF = 78.6     # 256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz
+
+
+def algorithmic_flops(H: int) -> float:
+    """full rollouts, one fused cost+constraint rollout per perturbation."""
+    return (1 + 6 * H) * (745 * H + 600 + 30 * (H + 1))
+
+
+def algorithmic_bytes(H: int) -> float:
+    """inputs read once + dense outputs (cost, grad, c, dc/dx) per eval."""
+    n, m = 6 * H, 12 * (H + 1)
+    return 8.0 * ((18 * H + 66) + (1 + n + m + m * n))
+
+
+def cpu_baseline(mp: MpcParams, hs, budget_s: float = 12.0):
+    """The reference-shaped numpy/scipy path (oracle/numpy_ref.py, pinned bit-for-bit to the real
+    reference) timed on one host core on a bounded sample of the same scenarios; the C port of the
+    same path is timed beside it.  The oracle is only the baseline here, never the product."""
+    from oracle.numpy_ref import NumpyRefMPC, base_traj_from_array
+    from oracle.oracle import COracle, ref_params_from
+
+    rp = ref_params_from(mp)
+    t0 = time.perf_counter()
+    done = 0
+    while done < hs.count and (time.perf_counter() - t0) < budget_s:
+        i = done
+        ref = NumpyRefMPC(rp)
+        ref.J_cached = hs.Jc[i].reshape(6, 6)
+        tgt = {"position": hs.target[i, :3], "orientation": hs.target[i, 3:]}
+        ref.fd_eval(hs.x[i], hs.state0[i], tgt, base_traj_from_array(hs.base_traj[i]), fast_constraint=False)
+        done += 1
+    t_np = time.perf_counter() - t0
+    co = COracle(rp)
+    nC = min(hs.count, 256)
+    t1 = time.perf_counter()
+    co.eval_fd(hs.as_oracle_dict(0, nC))
+    t_c = time.perf_counter() - t1
+    return {
+        "value": done / t_np, "unit": "evals/s", "cores": 1, "kind": "port",
+        "sample": f"{done} scenarios of the same batch, numpy restatement of ur_mpc.py with scipy approx_derivative "
+                  f"(1+n cost rollouts + 1+n constraint rollouts per eval), single thread, {t_np:.1f} s",
+        "c_port_value": nC / t_c, "c_port_sample": f"{nC} scenarios, scalar C port (oracle/mpc_oracle.c), single thread",
+        "host_cpus": os.cpu_count(),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--scenarios", type=int, default=65536, help="scenarios per GPU")
+    ap.add_argument("--horizon", type=int, default=20)
+    ap.add_argument("--motion", default="linear", choices=["linear", "angular"])
+    ap.add_argument("--algo", type=int, default=_ffi.ALGO_AUTO)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--only-main", action="store_true",
+                    help="run only the timed loop (profiling: every dispatch of the kernel is the benchmark's)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU: mpc_amd has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    H, S = args.horizon, args.scenarios
+    mp = MpcParams.reference_yaml_defaults(horizon=H, algo=args.algo)
+    ctx = MpcContext(mp, max_scenarios=S, device=local_rank)
+    # this rank's contiguous shard of the global scenario list (rows depend only on the global index)
+    hs = make_scenarios(mp, DeviceKinematics(ctx), S, motion=args.motion, cfg_id=2, first=rank * S)
+    sc, x = to_device(ctx, hs)
+    out = EvalResult(*(torch.empty(s, dtype=torch.float64, device=ctx.device)
+                       for s in ((S,), (S, mp.n), (S, mp.m), (S, mp.n, mp.m))))
+
+    def step():
+        ctx.eval_fd(sc, x, out=out)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()                       # the kernels are launched on torch's current stream
+    for _ in range(args.steps):
+        step()
+    ev1.record()
+    gathered = None
+    if dist is not None:               # the one exchange of the job: per-scenario results to every rank
+        gathered = torch.empty(world * S, dtype=torch.float64, device=ctx.device)
+        dist.all_gather_into_tensor(gathered, out.cost)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    kernel_ms = ev0.elapsed_time(ev1) / args.steps
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=ctx.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # sanity: the timed outputs are finite and the gather is the concatenation of the shards
+    assert bool(torch.isfinite(out.cost).all()) and bool(torch.isfinite(out.grad).all())
+    if gathered is not None:
+        assert torch.equal(gathered[rank * S:(rank + 1) * S], out.cost)
+
+    if rank == 0:
+        total_evals = world * S * args.steps
+        value = total_evals / elapsed
+        abytes, aflops = algorithmic_bytes(H), algorithmic_flops(H)
+        achieved = abytes * S / (kernel_ms * 1e-3) / 1e9
+        line = {
+            "metric": "objective+gradient evals/sec (f, c, FD grad f, dense FD dc/dx per scenario)",
+            "value": value, "unit": "evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"{args.motion}-platform-motion scenarios, H={H}, objective+FD gradient+dense FD "
+                                   f"constraint Jacobian, {S} scenarios per GPU resident in HBM (north_star target size)",
+                       "horizon": H, "scenarios_per_gpu": S, "n_vars": mp.n, "n_constraints": mp.m,
+                       "algo": "prefix" if ctx.params.algo != _ffi.ALGO_ROLLOUT else "rollout",
+                       "parallelism": f"scenario-dp{world}"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel_ms": kernel_ms, "algorithmic_bytes_per_eval": abytes,
+                         "fp64_valu": {"achieved_tflops_algorithmic": aflops * S / (kernel_ms * 1e-3) / 1e12,
+                                       "peak_tflops": FP64_VALU_PEAK_TF, "algorithmic_flops_per_eval": aflops}},
+        }
+        if args.only_main:
+            print(json.dumps(line), flush=True)
+            return
+        # compute-side view: same evals without the dense dc/dx stream (gradient + constraints only)
+        out2 = EvalResult(out.cost, out.grad, out.con, None)
+        for _ in range(2):
+            ctx.eval_fd(sc, x, want_jac=False, out=out2)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(args.steps):
+            ctx.eval_fd(sc, x, want_jac=False, out=out2)
+        e1.record()
+        torch.cuda.synchronize()
+        ms_nj = e0.elapsed_time(e1) / args.steps
+        line["no_dense_jacobian"] = {"evals_per_s": S / (ms_nj * 1e-3), "kernel_ms": ms_nj,
+                                     "fp64_tflops_algorithmic": aflops * S / (ms_nj * 1e-3) / 1e12,
+                                     "frac_of_fp64_valu_peak": aflops * S / (ms_nj * 1e-3) / 1e12 / FP64_VALU_PEAK_TF}
+        if S > 4096:   # configs[1] of BASELINE.json: 4,096 scenarios on one GPU
+            sc4, x4 = sc.slice(0, 4096), x[:4096]
+            o4 = EvalResult(out.cost[:4096], out.grad[:4096], out.con[:4096], out.con_jac[:4096])
+            for _ in range(3):
+                ctx.eval_fd(sc4, x4, out=o4)
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(args.steps):
+                ctx.eval_fd(sc4, x4, out=o4)
+            e1.record()
+            torch.cuda.synchronize()
+            line["evals_per_s_4096_scenarios"] = 4096 / (e0.elapsed_time(e1) / args.steps * 1e-3)
+        if not args.no_cpu_baseline and world == 1:
+            line["cpu_baseline"] = cpu_baseline(mp, hs)
+            line["speedup_vs_cpu_core"] = value / world / line["cpu_baseline"]["value"]
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -17,7 +17,7 @@ _UNITS = {
     "mpc_abi.hip": [],
     "kernels_rollout.hip": _STRICT,
     "kernels_aux.hip": _STRICT,
-    "kernels_prefix.hip": [],
+    "kernels_prefix.hip": _STRICT,  # fused multiply-adds are written out with fma() there
 }
 _COMMON = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function",
            "-I" + os.path.join(_ROOT, "include"), "-I" + CSRC]

@@ -1,14 +1,508 @@
-// MPC_ALGO_PREFIX — placeholder until the shared-prefix kernel lands.
+// MPC_ALGO_PREFIX — one workgroup per scenario (several scenarios when the horizon is short).
+//
+// scipy's forward difference perturbs ONE control u_j[a] per rollout, and a perturbation at step j
+// leaves every state before step j untouched.  So the unperturbed rollout is evaluated once
+// (phase 1: one lane per horizon step, per-step results parked in LDS), and every perturbed
+// rollout restarts from the shared prefix at its own step j (phase 2: one lane per PAIR of
+// perturbations (j, H-1-j) of one joint, so that every lane walks H+3 steps in all and the wave
+// stays full).  Per step a perturbed lane needs one new sin/cos (its own joint); the other five
+// joints, the platform yaw and Jc u_k come from LDS.  Phase 3 writes the dense dc/dx (mostly
+// structural zeros) cooperatively with 16-byte coalesced stores from the non-zeros staged in LDS.
+//
+// Arithmetic: fp64, explicit fma() in the kinematic chain (this unit is compiled with
+// -ffp-contract=off, so phase 1 and phase 2 run bit-identical code on identical inputs and a zero
+// step reproduces f0 exactly); sums that the reference orders (stage terms, stage totals, Euler
+// updates) keep the reference's order.  Differences from the CPU oracle are a few ulp of f.
+//
+// Restates: MPC:665-692 (_cost_function), MPC:249-381 (stage/terminal cost), DYN:101-128 (Euler
+// step), MPC:388-411 (constraint), NUMDIFF:44-72,498-524,584-625 (scipy's forward difference).
+#include "mpc_device.hpp"
 #include "mpc_kernels.hpp"
+
+namespace {
+
+using namespace mpcdev;
+
+constexpr int kMaxLdsBytes = 64 * 1024;
+
+struct PrefixArgs {
+    const double *decay;
+    mpc_scenarios sc;
+    const double *x;
+    double *cost;
+    double *grad;
+    double *con;
+    double *jac;
+    int S;      // scenarios per workgroup
+    int items;  // phase-2 lanes per scenario = 6 * ceil(H/2)
+};
+
+// LDS layout of one scenario (offsets in doubles)
+struct Layout {
+    int xs, bt, ys, st0, tgt, Jc, up, scs, po, qs, qn, Cp, vv, tb, lb, dxs, jvel, jpos, total;
+};
+
+__host__ __device__ inline Layout make_layout(int H, bool fd, bool same_dt)
+{
+    Layout Y;
+    int o = 0;
+    Y.xs = o;   o += 6 * H;         // control sequence
+    Y.bt = o;   o += 12 * H;        // platform trajectory
+    Y.ys = o;   o += 2 * H;         // cos, sin of the platform yaw per step
+    Y.st0 = o;  o += 18;
+    Y.tgt = o;  o += 6;
+    Y.Jc = o;   o += 36;
+    Y.up = o;   o += 6;
+    Y.scs = o;  o += 12 * (H + 1);  // sin[6], cos[6] of the unperturbed joint angles per step
+    Y.po = o;   o += 6 * (H + 1);   // unperturbed end-effector pose per step
+    Y.qs = o;   o += 6 * (H + 1);   // unperturbed joint angles, cost rollout (dt_cost)
+    Y.qn = o;   o += same_dt ? 0 : 6 * (H + 1);  // same, constraint rollout (dt_con)
+    Y.Cp = o;   o += H + 2;         // Cp[k] = L_0 + ... + L_{k-1}; Cp[H+1] = f0
+    Y.vv = o;   o += 6 * H;         // Jc @ u_k
+    Y.tb = o;                       // phase-1 scratch: Euler increments [6H] + step costs [H+1]
+    Y.lb = o + 6 * H;
+    const int scratch = 7 * H + 1;
+    if (fd) {
+        Y.dxs = o;                  // dx of every variable (aliases nothing: read in phase 3)
+        o += 6 * H;
+        Y.jvel = o; o += 6 * H;     // d(vel row of state j+1)/d u_j[a]
+        Y.jpos = o;                 // d(pos row of state k)/d u_j[a], k > j, packed [a][tri(j,k)]
+        const int tri = 3 * H * (H + 1);
+        // phase-1 scratch lives inside jpos when it fits (it is dead before phase 2 starts)
+        Y.tb = Y.jpos;
+        Y.lb = Y.jpos + 6 * H;
+        o += (tri > scratch) ? tri : scratch;
+    } else {
+        Y.dxs = Y.jvel = Y.jpos = o;
+        o += scratch;
+    }
+    Y.total = o;
+    return Y;
+}
+
+// ---- kinematics specialised to the UR twist pattern ------------------------------------------
+// alpha = (+90, 0, 0, +90, -90, 0) deg, a = (0, a2, a3, 0, 0, 0), d = (d1, 0, 0, d4, d5, d6).
+// Dropping the terms that are exactly zero / one leaves the generic DH product's values unchanged.
+template <int CA, int SA, bool HAS_A, bool HAS_D>
+__device__ __forceinline__ void ur_link(double (&R)[3][3], double (&o)[3], double c, double s, double a, double d)
+{
+    const double tx = a * c, ty = a * s;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const double r0 = R[r][0], r1 = R[r][1], r2 = R[r][2];
+        if (HAS_A) {
+            double inc = fma(r1, ty, r0 * tx);
+            if (HAS_D) inc = fma(r2, d, inc);
+            o[r] = o[r] + inc;
+        } else if (HAS_D) {
+            o[r] = fma(r2, d, o[r]);
+        }
+        R[r][0] = fma(r1, s, r0 * c);
+        if (CA == 1) {  // alpha = 0
+            R[r][1] = fma(r1, c, -(r0 * s));
+            R[r][2] = r2;
+        } else if (SA > 0) {  // alpha = +90 deg
+            R[r][1] = r2;
+            R[r][2] = fma(r0, s, -(r1 * c));
+        } else {  // alpha = -90 deg
+            R[r][1] = -r2;
+            R[r][2] = fma(r1, c, -(r0 * s));
+        }
+    }
+}
+
+// w = J(q) @ u accumulated while walking the chain:
+//   w_ang = sum_i u_i z_i,  w_lin = sum_i u_i z_i x (pe - o_i) = w_ang x pe - sum_i (u_i z_i) x o_i
+__device__ __forceinline__ void ur_twist(const mpc_params &P, const double (&sn)[6], const double (&cs)[6],
+                                         const double (&u)[6], double (&w)[6])
+{
+    double R[3][3] = {{P.base_c, -P.base_s, 0.0}, {P.base_s, P.base_c, 0.0}, {0.0, 0.0, 1.0}};
+    double o[3] = {0.0, 0.0, 0.0};
+    double om[3] = {0.0, 0.0, 0.0}, mm[3] = {0.0, 0.0, 0.0};
+    auto joint = [&](int i) {
+        const double z0 = u[i] * R[0][2], z1 = u[i] * R[1][2], z2 = u[i] * R[2][2];
+        om[0] += z0; om[1] += z1; om[2] += z2;
+        if (i > 0) {  // o_0 = 0
+            mm[0] = fma(z1, o[2], fma(-z2, o[1], mm[0]));
+            mm[1] = fma(z2, o[0], fma(-z0, o[2], mm[1]));
+            mm[2] = fma(z0, o[1], fma(-z1, o[0], mm[2]));
+        }
+    };
+    joint(0); ur_link<0, 1, false, true>(R, o, cs[0], sn[0], 0.0, P.dh_d[0]);
+    joint(1); ur_link<1, 0, true, false>(R, o, cs[1], sn[1], P.dh_a[1], 0.0);
+    joint(2); ur_link<1, 0, true, false>(R, o, cs[2], sn[2], P.dh_a[2], 0.0);
+    joint(3); ur_link<0, 1, false, true>(R, o, cs[3], sn[3], 0.0, P.dh_d[3]);
+    joint(4); ur_link<0, -1, false, true>(R, o, cs[4], sn[4], 0.0, P.dh_d[4]);
+    joint(5); ur_link<1, 0, false, true>(R, o, cs[5], sn[5], 0.0, P.dh_d[5]);
+    double pe[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) pe[r] = fma(R[r][2], P.tool[2], fma(R[r][1], P.tool[1], fma(R[r][0], P.tool[0], o[r])));
+    w[0] = fma(om[1], pe[2], -(om[2] * pe[1])) - mm[0];
+    w[1] = fma(om[2], pe[0], -(om[0] * pe[2])) - mm[1];
+    w[2] = fma(om[0], pe[1], -(om[1] * pe[0])) - mm[2];
+    w[3] = om[0]; w[4] = om[1]; w[5] = om[2];
+}
+
+// Stage cost L_k (stage = true, MPC:249-328) or terminal cost (MPC:330-381) with one code path:
+// the terminal form is the stage form with decay -> (terminal_factor, 1), no control terms, and
+// V = J(q_H) dq_H instead of Jc u_k.  Adding the three +0.0 terms leaves the value unchanged.
+__device__ __forceinline__ double unit_cost(const mpc_params &P, bool stage, const double (&V)[6],
+                                            const double (&u)[6], const double (&p)[3], const double (&o)[3],
+                                            const double *b, double cy, double sy, const double *tgt, double dk,
+                                            bool damp, const double *up, bool smooth)
+{
+    const double r0 = p[0] - b[0], r1 = p[1] - b[1], r2 = p[2] - b[2];
+    const double O0 = b[9], O1 = b[10], O2 = b[11];
+    const double x0 = O1 * r2 - O2 * r1;
+    const double x1 = O2 * r0 - O0 * r2;
+    const double x2 = O0 * r1 - O1 * r0;
+    const double w0 = -(b[6] + x0), w1 = -(b[7] + x1), w2 = -(b[8] + x2);
+    const double a0 = -O0, a1 = -O1, a2 = -O2;
+    const double tl0 = (cy * w0 + sy * w1) + 0.0 * w2;
+    const double tl1 = (-sy * w0 + cy * w1) + 0.0 * w2;
+    const double tl2 = (0.0 * w0 + 0.0 * w1) + 1.0 * w2;
+    const double ta0 = (cy * a0 + sy * a1) + 0.0 * a2;
+    const double ta1 = (-sy * a0 + cy * a1) + 0.0 * a2;
+    const double ta2 = (0.0 * a0 + 0.0 * a1) + 1.0 * a2;
+    const double fv = stage ? dk : P.terminal_factor;
+    const double fp = stage ? dk : 1.0;
+    const double c_lin = P.w_linear * fv * sumsq3(V[0] - tl0, V[1] - tl1, V[2] - tl2);
+    const double c_ang = P.w_angular * fv * sumsq3(V[3] - ta0, V[4] - ta1, V[5] - ta2);
+    const double c_pos = P.w_position * fp * sumsq3(p[0] - tgt[0], p[1] - tgt[1], p[2] - tgt[2]);
+    const double c_ori = P.w_orientation * fp * sumsq3(o[0] - tgt[3], o[1] - tgt[4], o[2] - tgt[5]);
+    const double uu = sumsq6(u);
+    const double c_ctl = stage ? P.w_control * uu : 0.0;
+    double du[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) du[j] = u[j] - up[j];
+    const double c_damp = damp ? P.w_damping * sumsq6(du) : 0.0;
+    const double c_smooth = smooth ? P.w_smooth * uu : 0.0;
+    return (((((c_lin + c_ang) + c_pos) + c_ori) + c_ctl) + c_damp) + c_smooth;
+}
+
+__device__ __forceinline__ double pick6(const double (&a)[6], int j)
+{
+    double v = a[0];
+#pragma unroll
+    for (int c = 1; c < 6; ++c) v = (j == c) ? a[c] : v;
+    return v;
+}
+
+template <bool FD, bool SAME_DT>
+__global__ __launch_bounds__(128) void prefix_kernel(const mpc_params P, const PrefixArgs A)
+{
+    extern __shared__ double lds[];
+    const int H = P.horizon, n = 6 * H, m = 12 * (H + 1), L = H + 1;
+    const int tid = threadIdx.x, bs = blockDim.x;
+    const Layout Y = make_layout(H, FD, SAME_DT);
+    double *dec = lds;  // [H], shared by the scenarios of the workgroup
+    double *scen = lds + H;
+    const int s0 = blockIdx.x * A.S;
+    const int ns = min(A.S, A.sc.count - s0);
+
+    // ---- stage the scenarios' inputs: rows of consecutive scenarios are contiguous in HBM ------
+    for (int i = tid; i < H; i += bs) dec[i] = A.decay[i];
+    for (int f = tid; f < ns * n; f += bs) {
+        const int ls = f / n;
+        scen[ls * Y.total + Y.xs + (f - ls * n)] = A.x[(size_t)s0 * n + f];
+    }
+    for (int f = tid; f < ns * 12 * H; f += bs) {
+        const int ls = f / (12 * H);
+        scen[ls * Y.total + Y.bt + (f - ls * 12 * H)] = A.sc.base_traj[(size_t)s0 * 12 * H + f];
+    }
+    for (int f = tid; f < ns * 18; f += bs) scen[(f / 18) * Y.total + Y.st0 + f % 18] = A.sc.state0[(size_t)s0 * 18 + f];
+    for (int f = tid; f < ns * 6; f += bs) scen[(f / 6) * Y.total + Y.tgt + f % 6] = A.sc.target[(size_t)s0 * 6 + f];
+    for (int f = tid; f < ns * 36; f += bs) scen[(f / 36) * Y.total + Y.Jc + f % 36] = A.sc.Jc[(size_t)s0 * 36 + f];
+    const bool any_prev = A.sc.u_prev != nullptr && A.sc.has_prev != nullptr;
+    for (int f = tid; f < ns * 6; f += bs)
+        scen[(f / 6) * Y.total + Y.up + f % 6] = any_prev ? A.sc.u_prev[(size_t)s0 * 6 + f] : 0.0;
+    __syncthreads();
+    for (int f = tid; f < ns * H; f += bs) {
+        const int ls = f / H, k = f - ls * H;
+        double *S = scen + ls * Y.total;
+        double sy, cy;
+        sincos(S[Y.bt + 12 * k + 5], &sy, &cy);
+        S[Y.ys + 2 * k] = cy;
+        S[Y.ys + 2 * k + 1] = sy;
+    }
+
+    // ================= phase 1: the unperturbed rollout, one lane per step =====================
+    const bool act1 = tid < ns * L;
+    const int ls1 = act1 ? tid / L : 0;
+    const int k1 = act1 ? tid - ls1 * L : 0;
+    double *S1 = scen + ls1 * Y.total;
+    const bool has_prev1 = any_prev && A.sc.has_prev[s0 + ls1] != 0;
+    double u1[6], w1[6], vc1[6];
+    if (act1) {
+        const int k = k1;
+        double qc[6], qn[6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) { qc[j] = S1[Y.st0 + j]; qn[j] = qc[j]; }
+        for (int jj = 0; jj < k; ++jj) {
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                const double uj = S1[Y.xs + 6 * jj + j];
+                qc[j] = qc[j] + uj * P.dt_cost;            // DYN:105
+                if (!SAME_DT) qn[j] = qn[j] + uj * P.dt_con;
+            }
+        }
+        double sn[6], cs[6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            sincos(qc[j], &sn[j], &cs[j]);
+            S1[Y.qs + 6 * k + j] = qc[j];
+            if (!SAME_DT) S1[Y.qn + 6 * k + j] = qn[j];
+            S1[Y.scs + 12 * k + j] = sn[j];
+            S1[Y.scs + 12 * k + 6 + j] = cs[j];
+        }
+        const int ku = (k < H) ? k : H - 1;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) u1[j] = S1[Y.xs + 6 * ku + j];
+        ur_twist(P, sn, cs, u1, w1);
+        if (k < H) {
+#pragma unroll
+            for (int c = 0; c < 6; ++c) {
+                vc1[c] = dot6(S1 + Y.Jc + 6 * c, u1);     // MPC:260-261
+                S1[Y.vv + 6 * k + c] = vc1[c];
+                S1[Y.tb + 6 * k + c] = w1[c] * P.dt_cost;  // DYN:119-120
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < 6; ++c) vc1[c] = w1[c];    // terminal: J(q_H) dq_H (MPC:344-345)
+        }
+        if (A.con != nullptr) {                            // MPC:394-409
+            double2 *dst = reinterpret_cast<double2 *>(A.con + (size_t)(s0 + ls1) * m + 12 * k);
+            double c0[12];
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                const double dq = (k == 0) ? S1[Y.st0 + 6 + j] : S1[Y.xs + 6 * (k - 1) + j];
+                c0[j] = con_pos(P, j, SAME_DT ? qc[j] : qn[j]);
+                c0[6 + j] = con_vel(P, j, dq);
+            }
+#pragma unroll
+            for (int t = 0; t < 6; ++t) dst[t] = make_double2(c0[2 * t], c0[2 * t + 1]);
+        }
+    }
+    __syncthreads();
+    if (act1) {
+        const int k = k1;
+        double p[3] = {S1[Y.st0 + 12], S1[Y.st0 + 13], S1[Y.st0 + 14]};
+        double o[3] = {S1[Y.st0 + 15], S1[Y.st0 + 16], S1[Y.st0 + 17]};
+        for (int jj = 0; jj < k; ++jj) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                p[c] = p[c] + S1[Y.tb + 6 * jj + c];
+                o[c] = o[c] + S1[Y.tb + 6 * jj + 3 + c];
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { S1[Y.po + 6 * k + c] = p[c]; S1[Y.po + 6 * k + 3 + c] = o[c]; }
+        const int kb = (k < H) ? k : H - 1;                // terminal uses B_{H-1} (MPC:689)
+        const double Lk = unit_cost(P, k < H, vc1, u1, p, o, S1 + Y.bt + 12 * kb, S1[Y.ys + 2 * kb],
+                                    S1[Y.ys + 2 * kb + 1], S1 + Y.tgt, dec[kb], k > 0 && k < H && has_prev1,
+                                    S1 + Y.up, k > 0 && k < H && H > 1);
+        S1[Y.lb + k] = Lk;
+    }
+    __syncthreads();
+    if (act1) {
+        const int k = k1;
+        double tot = 0.0;
+        for (int jj = 0; jj < k; ++jj) tot = tot + S1[Y.lb + jj];  // MPC:683, left to right
+        if (k == H) {
+            const double f0 = tot + S1[Y.lb + H];                   // MPC:690
+            A.cost[s0 + ls1] = f0;
+            S1[Y.Cp + H + 1] = f0;
+        }
+        // Cp lives apart from lb (which aliases jpos): every lane has read lb before any writes jpos
+        S1[Y.Cp + k] = tot;
+    }
+    if (!FD) return;
+    __syncthreads();
+
+    // ================= phase 2: perturbed rollouts from the shared prefix ======================
+    const bool act2 = tid < ns * A.items;
+    const int ls2 = act2 ? tid / A.items : 0;
+    const int it = act2 ? tid - ls2 * A.items : 0;
+    const int pi = it / 6, a = it - 6 * pi;
+    double *S2 = scen + ls2 * Y.total;
+    const bool has_prev2 = any_prev && A.sc.has_prev[s0 + ls2] != 0;
+    const int j_first = pi, j_second = H - 1 - pi;
+    const int npert = (j_second > j_first) ? 2 : 1;
+    const double lim = pick6(P.v_lim, a), qlo = pick6(P.q_lo, a), qhi = pick6(P.q_hi, a);
+    const double f0 = S2[Y.Cp + H + 1];
+    const int tri_a = a * (H * (H + 1) / 2);
+
+    bool active = act2, need_init = true;
+    int pert = 0, j = 0, k = 0, var = 0, tri_j = 0;
+    double acc = 0.0, xv = 0.0, x0v = 0.0, dx = 1.0;
+    double p[3] = {0, 0, 0}, o[3] = {0, 0, 0};
+    double qc = 0.0, qnp = 0.0, qnb = 0.0;
+    const int iters = H + 3;
+    for (int step = 0; step < iters; ++step) {
+        if (!active) continue;
+        if (need_init) {
+            j = (pert == 0) ? j_first : j_second;
+            var = 6 * j + a;
+            x0v = S2[Y.xs + var];
+            xv = x0v + fd_step(x0v, -lim, lim, P.fd_eps);   // NUMDIFF:594
+            dx = xv - x0v;                                   // NUMDIFF:596
+            S2[Y.dxs + var] = dx;
+            k = j;
+            acc = S2[Y.Cp + j];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { p[c] = S2[Y.po + 6 * j + c]; o[c] = S2[Y.po + 6 * j + 3 + c]; }
+            qc = S2[Y.qs + 6 * j + a];
+            qnb = SAME_DT ? qc : S2[Y.qn + 6 * j + a];
+            qnp = qnb;
+            tri_j = tri_a + j * H - (j * (j - 1)) / 2 - j - 1;  // + k gives the packed index of (j, k)
+            need_init = false;
+        }
+        // ---- step k of this perturbed rollout ----
+        const int ku = (k < H) ? k : H - 1;
+        double u[6], sn[6], cs[6];
+        double sa, ca;
+        sincos(qc, &sa, &ca);
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+            const double ub = S2[Y.xs + 6 * ku + c];
+            u[c] = (c == a && ku == j) ? xv : ub;
+            const double sb = S2[Y.scs + 12 * k + c], cb = S2[Y.scs + 12 * k + 6 + c];
+            sn[c] = (c == a) ? sa : sb;
+            cs[c] = (c == a) ? ca : cb;
+        }
+        double w[6], V[6];
+        ur_twist(P, sn, cs, u, w);
+        const double du = (k == j) ? dx : 0.0;
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+            // Jc @ u'_k = Jc @ u_k + Jc[:,a] (u'_k[a] - u_k[a]); the correction is zero off step j
+            const double vs = fma(S2[Y.Jc + 6 * c + a], du, S2[Y.vv + 6 * ku + c]);
+            V[c] = (k < H) ? vs : w[c];
+        }
+        const double Lk = unit_cost(P, k < H, V, u, p, o, S2 + Y.bt + 12 * ku, S2[Y.ys + 2 * ku],
+                                    S2[Y.ys + 2 * ku + 1], S2 + Y.tgt, dec[ku], k > 0 && k < H && has_prev2,
+                                    S2 + Y.up, k > 0 && k < H && H > 1);
+        acc = acc + Lk;
+        if (k < H) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                p[c] = p[c] + w[c] * P.dt_cost;
+                o[c] = o[c] + w[3 + c] * P.dt_cost;
+            }
+            const double ub = S2[Y.xs + 6 * k + a];
+            const double ua = (k == j) ? xv : ub;
+            qc = qc + ua * P.dt_cost;
+            if (SAME_DT) {
+                qnp = qc;
+                qnb = S2[Y.qs + 6 * (k + 1) + a];
+            } else {
+                qnp = qnp + ua * P.dt_con;
+                qnb = qnb + ub * P.dt_con;
+            }
+            // column `var` of dc/dx, rows of state k+1 (the other rows of the column are +-0)
+            const double c1 = fmin(qnp - qlo, qhi - qnp), c0 = fmin(qnb - qlo, qhi - qnb);
+            S2[Y.jpos + tri_j + (k + 1)] = (c1 - c0) / dx;
+            if (k == j) S2[Y.jvel + var] = ((lim - fabs(xv)) - (lim - fabs(x0v))) / dx;
+            k = k + 1;
+        } else {
+            if (A.grad != nullptr) A.grad[(size_t)(s0 + ls2) * n + var] = (acc - f0) / dx;  // NUMDIFF:619
+            pert = pert + 1;
+            if (pert < npert) need_init = true; else active = false;
+        }
+    }
+    if (A.jac == nullptr) return;
+    __syncthreads();
+
+    // ================= phase 3: dense dc/dx, column-major m x n per scenario ====================
+    // Each wave takes scenarios round-robin; a lane owns two consecutive rows (one 16-byte store)
+    // of every column, so its state index and row-in-state are fixed per pass.
+    const int lane = tid & 63, wave = tid >> 6, nwaves = bs >> 6;
+    for (int ls = wave; ls < ns; ls += nwaves) {
+        const double *S = scen + ls * Y.total;
+        double *out = A.jac + (size_t)(s0 + ls) * n * m;
+        for (int r0 = 2 * lane; r0 < m; r0 += 128) {
+            const int kk = r0 / 12, t = r0 - 12 * kk;  // rows r0, r0+1 = rows t, t+1 of state kk (t even)
+            for (int jj = 0; jj < H; ++jj) {
+                const bool below = kk > jj;            // position rows depend on u_jj only for kk > jj
+                const bool next = kk == jj + 1;        // velocity rows only for kk == jj + 1
+                const int tj = jj * H - (jj * (jj - 1)) / 2 - jj - 1 + kk;
+#pragma unroll
+                for (int aa = 0; aa < 6; ++aa) {
+                    const int col = 6 * jj + aa;
+                    const double z = copysign(0.0, S[Y.dxs + col]);   // (c - c)/dx = +-0
+                    double v0 = z, v1 = z;
+                    if (below && (t == aa || t + 1 == aa)) {
+                        const double pv = S[Y.jpos + aa * (H * (H + 1) / 2) + tj];
+                        if (t == aa) v0 = pv; else v1 = pv;
+                    }
+                    if (next && (t == 6 + aa || t + 1 == 6 + aa)) {
+                        const double vv = S[Y.jvel + col];
+                        if (t == 6 + aa) v0 = vv; else v1 = vv;
+                    }
+                    *reinterpret_cast<double2 *>(out + (size_t)col * m + r0) = make_double2(v0, v1);
+                }
+            }
+        }
+    }
+}
+
+bool ur_pattern(const mpc_params &P)
+{
+    const double ca[6] = {0, 1, 1, 0, 0, 1}, sa[6] = {1, 0, 0, 1, -1, 0};
+    for (int i = 0; i < 6; ++i) {
+        if (P.dh_ca[i] != ca[i] || P.dh_sa[i] != sa[i]) return false;
+        const bool has_a = (i == 1 || i == 2), has_d = !has_a;
+        if (!has_a && P.dh_a[i] != 0.0) return false;
+        if (!has_d && P.dh_d[i] != 0.0) return false;
+    }
+    return true;
+}
+
+struct Geometry { int S, items, threads; size_t lds; };
+
+Geometry geometry(const mpc_params &P, bool fd)
+{
+    const int H = P.horizon, L = H + 1;
+    const bool same_dt = P.dt_cost == P.dt_con;
+    Geometry g;
+    g.items = 6 * ((H + 1) / 2);
+    const int lanes = fd ? (g.items > L ? g.items : L) : L;  // lanes one scenario needs
+    g.S = lanes <= 64 ? 64 / lanes : 1;
+    g.threads = ((g.S * lanes + 63) / 64) * 64;
+    g.lds = sizeof(double) * ((size_t)H + (size_t)g.S * make_layout(H, fd, same_dt).total);
+    return g;
+}
+
+}  // namespace
 
 namespace mpck {
 
-bool prefix_supported(const mpc_params &) { return false; }
-
-hipError_t launch_prefix(const mpc_params &, const double *, const mpc_scenarios &, const double *, double *,
-                         double *, double *, double *, hipStream_t)
+bool prefix_supported(const mpc_params &P)
 {
-    return hipErrorNotSupported;
+    if (!ur_pattern(P)) return false;
+    const Geometry g = geometry(P, true);
+    return g.threads <= 128 && g.lds <= (size_t)kMaxLdsBytes;
+}
+
+hipError_t launch_prefix(const mpc_params &P, const double *decay, const mpc_scenarios &sc, const double *x,
+                         double *cost, double *grad, double *con, double *jac, hipStream_t stream)
+{
+    const bool fd = grad != nullptr || jac != nullptr;
+    const Geometry g = geometry(P, fd);
+    if (!ur_pattern(P) || g.threads > 128 || g.lds > (size_t)kMaxLdsBytes) return hipErrorNotSupported;
+    PrefixArgs A;
+    A.decay = decay; A.sc = sc; A.x = x; A.cost = cost; A.grad = grad; A.con = con; A.jac = jac;
+    A.S = g.S; A.items = g.items;
+    const unsigned grid = (unsigned)((sc.count + g.S - 1) / g.S);
+    const bool same_dt = P.dt_cost == P.dt_con;
+    if (fd) {
+        if (same_dt) hipLaunchKernelGGL((prefix_kernel<true, true>), dim3(grid), dim3(g.threads), g.lds, stream, P, A);
+        else hipLaunchKernelGGL((prefix_kernel<true, false>), dim3(grid), dim3(g.threads), g.lds, stream, P, A);
+    } else {
+        if (same_dt) hipLaunchKernelGGL((prefix_kernel<false, true>), dim3(grid), dim3(g.threads), g.lds, stream, P, A);
+        else hipLaunchKernelGGL((prefix_kernel<false, false>), dim3(grid), dim3(g.threads), g.lds, stream, P, A);
+    }
+    return hipGetLastError();
 }
 
 }  // namespace mpck
