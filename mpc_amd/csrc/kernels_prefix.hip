@@ -16,6 +16,8 @@
 //
 // Restates: MPC:665-692 (_cost_function), MPC:249-381 (stage/terminal cost), DYN:101-128 (Euler
 // step), MPC:388-411 (constraint), NUMDIFF:44-72,498-524,584-625 (scipy's forward difference).
+#include <cstdlib>
+
 #include "mpc_device.hpp"
 #include "mpc_kernels.hpp"
 
@@ -35,11 +37,12 @@ struct PrefixArgs {
     double *jac;
     int S;      // scenarios per workgroup
     int items;  // phase-2 lanes per scenario = 6 * ceil(H/2)
+    int debug;
 };
 
 // LDS layout of one scenario (offsets in doubles)
 struct Layout {
-    int xs, bt, ys, st0, tgt, Jc, up, scs, po, qs, qn, Cp, vv, tb, lb, dxs, jvel, jpos, total;
+    int xs, bt, ys, st0, tgt, Jc, up, scs, po, qs, qn, Cp, vv, tb, lb, jvel, jpos, total;
 };
 
 __host__ __device__ inline Layout make_layout(int H, bool fd, bool same_dt)
@@ -63,19 +66,19 @@ __host__ __device__ inline Layout make_layout(int H, bool fd, bool same_dt)
     Y.lb = o + 6 * H;
     const int scratch = 7 * H + 1;
     if (fd) {
-        Y.dxs = o;                  // dx of every variable (aliases nothing: read in phase 3)
-        o += 6 * H;
-        Y.jvel = o; o += 6 * H;     // d(vel row of state j+1)/d u_j[a]
-        Y.jpos = o;                 // d(pos row of state k)/d u_j[a], k > j, packed [a][tri(j,k)]
+        o += o & 1;                 // 16-byte alignment of the two arrays phase 3 reads as pairs
+        Y.jvel = o; o += 6 * H;     // d(vel row of state j+1)/d u_j[a], [j][a]
+        Y.jpos = o;                 // d(pos row of state k)/d u_j[a], k > j, packed [tri(j,k)][a]
         const int tri = 3 * H * (H + 1);
         // phase-1 scratch lives inside jpos when it fits (it is dead before phase 2 starts)
         Y.tb = Y.jpos;
         Y.lb = Y.jpos + 6 * H;
         o += (tri > scratch) ? tri : scratch;
     } else {
-        Y.dxs = Y.jvel = Y.jpos = o;
+        Y.jvel = Y.jpos = o;
         o += scratch;
     }
+    o += o & 1;
     Y.total = o;
     return Y;
 }
@@ -191,12 +194,12 @@ __device__ __forceinline__ double pick6(const double (&a)[6], int j)
 template <bool FD, bool SAME_DT>
 __global__ __launch_bounds__(128) void prefix_kernel(const mpc_params P, const PrefixArgs A)
 {
-    extern __shared__ double lds[];
+    extern __shared__ __align__(16) double lds[];
     const int H = P.horizon, n = 6 * H, m = 12 * (H + 1), L = H + 1;
     const int tid = threadIdx.x, bs = blockDim.x;
     const Layout Y = make_layout(H, FD, SAME_DT);
     double *dec = lds;  // [H], shared by the scenarios of the workgroup
-    double *scen = lds + H;
+    double *scen = lds + ((H + 1) & ~1);
     const int s0 = blockIdx.x * A.S;
     const int ns = min(A.S, A.sc.count - s0);
 
@@ -330,14 +333,13 @@ __global__ __launch_bounds__(128) void prefix_kernel(const mpc_params P, const P
     const int npert = (j_second > j_first) ? 2 : 1;
     const double lim = pick6(P.v_lim, a), qlo = pick6(P.q_lo, a), qhi = pick6(P.q_hi, a);
     const double f0 = S2[Y.Cp + H + 1];
-    const int tri_a = a * (H * (H + 1) / 2);
 
     bool active = act2, need_init = true;
     int pert = 0, j = 0, k = 0, var = 0, tri_j = 0;
     double acc = 0.0, xv = 0.0, x0v = 0.0, dx = 1.0;
     double p[3] = {0, 0, 0}, o[3] = {0, 0, 0};
     double qc = 0.0, qnp = 0.0, qnb = 0.0;
-    const int iters = H + 3;
+    const int iters = (A.debug & 1) ? 0 : H + 3;
     for (int step = 0; step < iters; ++step) {
         if (!active) continue;
         if (need_init) {
@@ -346,7 +348,6 @@ __global__ __launch_bounds__(128) void prefix_kernel(const mpc_params P, const P
             x0v = S2[Y.xs + var];
             xv = x0v + fd_step(x0v, -lim, lim, P.fd_eps);   // NUMDIFF:594
             dx = xv - x0v;                                   // NUMDIFF:596
-            S2[Y.dxs + var] = dx;
             k = j;
             acc = S2[Y.Cp + j];
 #pragma unroll
@@ -354,7 +355,7 @@ __global__ __launch_bounds__(128) void prefix_kernel(const mpc_params P, const P
             qc = S2[Y.qs + 6 * j + a];
             qnb = SAME_DT ? qc : S2[Y.qn + 6 * j + a];
             qnp = qnb;
-            tri_j = tri_a + j * H - (j * (j - 1)) / 2 - j - 1;  // + k gives the packed index of (j, k)
+            tri_j = j * H - (j * (j - 1)) / 2 - j - 1;  // + k gives the packed index of (j, k)
             need_init = false;
         }
         // ---- step k of this perturbed rollout ----
@@ -401,7 +402,7 @@ __global__ __launch_bounds__(128) void prefix_kernel(const mpc_params P, const P
             }
             // column `var` of dc/dx, rows of state k+1 (the other rows of the column are +-0)
             const double c1 = fmin(qnp - qlo, qhi - qnp), c0 = fmin(qnb - qlo, qhi - qnb);
-            S2[Y.jpos + tri_j + (k + 1)] = (c1 - c0) / dx;
+            S2[Y.jpos + 6 * (tri_j + k + 1) + a] = (c1 - c0) / dx;
             if (k == j) S2[Y.jvel + var] = ((lim - fabs(xv)) - (lim - fabs(x0v))) / dx;
             k = k + 1;
         } else {
@@ -410,36 +411,59 @@ __global__ __launch_bounds__(128) void prefix_kernel(const mpc_params P, const P
             if (pert < npert) need_init = true; else active = false;
         }
     }
-    if (A.jac == nullptr) return;
+    if (A.jac == nullptr || (A.debug & 2)) return;
     __syncthreads();
 
     // ================= phase 3: dense dc/dx, column-major m x n per scenario ====================
-    // Each wave takes scenarios round-robin; a lane owns two consecutive rows (one 16-byte store)
-    // of every column, so its state index and row-in-state are fixed per pass.
+    // Each wave takes scenarios round-robin; per pass a lane owns two consecutive rows (one
+    // 16-byte store) of EVERY column: rows (t, t+1) of state kk, i.e. the position (t < 6) or
+    // velocity (t >= 6) rows of the joint pair (2gp, 2gp+1).  Column (jj, aa) is non-zero in this
+    // piece only for aa in that pair, and only if kk > jj (position) or kk == jj+1 (velocity), so
+    // one 16-byte LDS read per (jj, pass) feeds the lane's six stores of that step.
+    // Structural zeros are written as +0.0 (scipy's quotient (c - c)/dx gives -0.0 where the step
+    // was flipped; the two compare equal).
+    // Columns are written in ascending order with all of a column's rows back to back, so that the
+    // 128-byte lines shared by neighbouring columns (a column is 12(H+1)*8 bytes, not a multiple of
+    // 128) are completed while they are still in L2.
+    typedef double v2d __attribute__((ext_vector_type(2)));
+    constexpr int kMaxPass = 4;  // rows per pass = 128; prefix_supported() keeps 12(H+1) <= 512
     const int lane = tid & 63, wave = tid >> 6, nwaves = bs >> 6;
+    const int npass = (m + 127) / 128;
     for (int ls = wave; ls < ns; ls += nwaves) {
         const double *S = scen + ls * Y.total;
         double *out = A.jac + (size_t)(s0 + ls) * n * m;
-        for (int r0 = 2 * lane; r0 < m; r0 += 128) {
-            const int kk = r0 / 12, t = r0 - 12 * kk;  // rows r0, r0+1 = rows t, t+1 of state kk (t even)
-            for (int jj = 0; jj < H; ++jj) {
-                const bool below = kk > jj;            // position rows depend on u_jj only for kk > jj
-                const bool next = kk == jj + 1;        // velocity rows only for kk == jj + 1
-                const int tj = jj * H - (jj * (jj - 1)) / 2 - jj - 1 + kk;
+        int kk[kMaxPass], gp[kMaxPass];
+        bool is_pos[kMaxPass], live[kMaxPass];
+        const double *src[kMaxPass];
 #pragma unroll
-                for (int aa = 0; aa < 6; ++aa) {
-                    const int col = 6 * jj + aa;
-                    const double z = copysign(0.0, S[Y.dxs + col]);   // (c - c)/dx = +-0
-                    double v0 = z, v1 = z;
-                    if (below && (t == aa || t + 1 == aa)) {
-                        const double pv = S[Y.jpos + aa * (H * (H + 1) / 2) + tj];
-                        if (t == aa) v0 = pv; else v1 = pv;
+        for (int ps = 0; ps < kMaxPass; ++ps) {
+            const int r0 = 128 * ps + 2 * lane;
+            live[ps] = ps < npass && r0 < m;
+            kk[ps] = r0 / 12;
+            const int g = (r0 - 12 * kk[ps]) >> 1;
+            is_pos[ps] = g < 3;
+            gp[ps] = is_pos[ps] ? g : g - 3;
+            src[ps] = is_pos[ps] ? S + Y.jpos + 6 * kk[ps] + 2 * gp[ps] : S + Y.jvel + 2 * gp[ps];
+        }
+        for (int jj = 0; jj < H; ++jj) {
+            const int tj = jj * H - (jj * (jj - 1)) / 2 - jj - 1;
+            v2d val[kMaxPass];
+#pragma unroll
+            for (int ps = 0; ps < kMaxPass; ++ps) {
+                val[ps] = v2d{0.0, 0.0};
+                const bool hot = live[ps] && (is_pos[ps] ? (kk[ps] > jj) : (kk[ps] == jj + 1));
+                if (hot) val[ps] = *reinterpret_cast<const v2d *>(src[ps] + 6 * (is_pos[ps] ? tj : jj));
+            }
+#pragma unroll
+            for (int aa = 0; aa < 6; ++aa) {
+                double *col = out + (size_t)(6 * jj + aa) * m + 2 * lane;
+#pragma unroll
+                for (int ps = 0; ps < kMaxPass; ++ps) {
+                    if (ps < npass && live[ps]) {
+                        const bool mine = gp[ps] == (aa >> 1);
+                        const v2d v = (aa & 1) ? v2d{0.0, mine ? val[ps].y : 0.0} : v2d{mine ? val[ps].x : 0.0, 0.0};
+                        __builtin_nontemporal_store(v, reinterpret_cast<v2d *>(col + 128 * ps));
                     }
-                    if (next && (t == 6 + aa || t + 1 == 6 + aa)) {
-                        const double vv = S[Y.jvel + col];
-                        if (t == 6 + aa) v0 = vv; else v1 = vv;
-                    }
-                    *reinterpret_cast<double2 *>(out + (size_t)col * m + r0) = make_double2(v0, v1);
                 }
             }
         }
@@ -469,7 +493,7 @@ Geometry geometry(const mpc_params &P, bool fd)
     const int lanes = fd ? (g.items > L ? g.items : L) : L;  // lanes one scenario needs
     g.S = lanes <= 64 ? 64 / lanes : 1;
     g.threads = ((g.S * lanes + 63) / 64) * 64;
-    g.lds = sizeof(double) * ((size_t)H + (size_t)g.S * make_layout(H, fd, same_dt).total);
+    g.lds = sizeof(double) * ((size_t)((H + 1) & ~1) + (size_t)g.S * make_layout(H, fd, same_dt).total);
     return g;
 }
 
@@ -481,7 +505,7 @@ bool prefix_supported(const mpc_params &P)
 {
     if (!ur_pattern(P)) return false;
     const Geometry g = geometry(P, true);
-    return g.threads <= 128 && g.lds <= (size_t)kMaxLdsBytes;
+    return g.threads <= 128 && g.lds <= (size_t)kMaxLdsBytes && 12 * (P.horizon + 1) <= 512;
 }
 
 hipError_t launch_prefix(const mpc_params &P, const double *decay, const mpc_scenarios &sc, const double *x,
@@ -489,10 +513,11 @@ hipError_t launch_prefix(const mpc_params &P, const double *decay, const mpc_sce
 {
     const bool fd = grad != nullptr || jac != nullptr;
     const Geometry g = geometry(P, fd);
-    if (!ur_pattern(P) || g.threads > 128 || g.lds > (size_t)kMaxLdsBytes) return hipErrorNotSupported;
+    if (!prefix_supported(P)) return hipErrorNotSupported;
     PrefixArgs A;
     A.decay = decay; A.sc = sc; A.x = x; A.cost = cost; A.grad = grad; A.con = con; A.jac = jac;
     A.S = g.S; A.items = g.items;
+    { const char *e = getenv("MPC_AMD_DEBUG"); A.debug = e ? atoi(e) : 0; }
     const unsigned grid = (unsigned)((sc.count + g.S - 1) / g.S);
     const bool same_dt = P.dt_cost == P.dt_con;
     if (fd) {

@@ -1,0 +1,28 @@
+#!/bin/bash
+# usage: tools_pmc.sh <outdir> <prog args...>   -- runs the counter passes one by one
+set -e
+export TMPDIR=/tmp
+out=$1; shift
+mkdir -p $out
+i=0
+for set in \
+ "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU" \
+ "SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_SALU SQ_INSTS_VMEM_WR" \
+ "FETCH_SIZE" \
+ "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum" \
+ "GRBM_GUI_ACTIVE SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INST_CYCLES_VMEM_WR SQ_THREAD_CYCLES_VALU SQ_INSTS_VALU_INT32 SQ_ACTIVE_INST_VMEM"
+do
+  i=$((i+1))
+  timeout -s KILL 120 rocprofv3 --pmc $set --output-format csv -d $out/pass$i -- python3 tools/prof.py "$@" > $out/pass$i.log 2>&1 || { echo "pass $i failed"; tail -5 $out/pass$i.log; }
+done
+python3 - "$out" <<'PY'
+import csv, glob, sys, collections
+out = sys.argv[1]
+for f in sorted(glob.glob(out + "/pass*/**/*counter_collection.csv", recursive=True)):
+    agg = collections.defaultdict(list)
+    for row in csv.DictReader(open(f)):
+        if "prefix_kernel" in row["Kernel_Name"] or "rollout_kernel" in row["Kernel_Name"]:
+            agg[row["Counter_Name"]].append(float(row["Counter_Value"]))
+    for k, v in agg.items():
+        print(f"{k:32s} n={len(v)} mean={sum(v)/len(v):.6g}")
+PY

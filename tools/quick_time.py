@@ -1,4 +1,5 @@
 """Quick device timing of eval_fd (dev tool, not the benchmark contract)."""
+import os, sys; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import sys, time
 import numpy as np, torch
 from mpc_amd.batch import MpcContext, EvalResult

@@ -1,0 +1,67 @@
+// Dev microbenchmark: how fast can waves stream per-wave-private 241,920-byte blocks to HBM?
+// All accesses are in bounds by construction: block b covers [b*BLK, (b+1)*BLK) doubles of a
+// buffer of nblocks*BLK doubles.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+typedef double v2d __attribute__((ext_vector_type(2)));
+constexpr int BLK = 120 * 252;  // doubles per block
+
+// mode 0: flat aligned 1 KB stores; mode 1: 252-double columns as 64+62 lane stores;
+// mode 2: flat, but consecutive blocks of the grid interleave chunks (grid-stride over the whole buffer)
+template <int MODE>
+__global__ __launch_bounds__(64) void k(double *out, int nblocks, int lds_pad)
+{
+    extern __shared__ double pad[];
+    const int lane = threadIdx.x;
+    if (lds_pad < 0) pad[lane] = 1.0;  // keep the LDS allocation alive
+    const v2d z = {0.0, (double)lane};
+    if (MODE == 0) {
+        double *base = out + (size_t)blockIdx.x * BLK;
+        for (int c = 0; c < BLK / 128; ++c) *reinterpret_cast<v2d *>(base + 128 * c + 2 * lane) = z;
+        const int rem = BLK - (BLK / 128) * 128;  // 32 doubles
+        if (2 * lane < rem) *reinterpret_cast<v2d *>(base + (BLK / 128) * 128 + 2 * lane) = z;
+    } else if (MODE == 1) {
+        double *base = out + (size_t)blockIdx.x * BLK;
+        for (int col = 0; col < 120; ++col) {
+            double *dst = base + col * 252;
+            *reinterpret_cast<v2d *>(dst + 2 * lane) = z;
+            if (lane < 62) *reinterpret_cast<v2d *>(dst + 128 + 2 * lane) = z;
+        }
+    } else {
+        const size_t total = (size_t)nblocks * BLK / 2;  // v2d elements
+        v2d *o = reinterpret_cast<v2d *>(out);
+        for (size_t i = (size_t)blockIdx.x * 64 + lane; i < total; i += (size_t)gridDim.x * 64) o[i] = z;
+    }
+}
+
+int main(int argc, char **argv)
+{
+    const int nblocks = 65536;
+    double *buf;
+    if (hipMalloc(&buf, sizeof(double) * (size_t)nblocks * BLK) != hipSuccess) { printf("alloc failed\n"); return 1; }
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    const size_t bytes = sizeof(double) * (size_t)nblocks * BLK;
+    for (int lds : {0, 21 * 1024, 40 * 1024}) {
+        for (int mode = 0; mode < 3; ++mode) {
+            float best = 1e9;
+            for (int rep = 0; rep < 4; ++rep) {
+                hipEventRecord(e0);
+                if (mode == 0) hipLaunchKernelGGL(k<0>, dim3(nblocks), dim3(64), lds, 0, buf, nblocks, 0);
+                if (mode == 1) hipLaunchKernelGGL(k<1>, dim3(nblocks), dim3(64), lds, 0, buf, nblocks, 0);
+                if (mode == 2) hipLaunchKernelGGL(k<2>, dim3(256 * 8), dim3(64), lds, 0, buf, nblocks, 0);
+                hipEventRecord(e1);
+                hipEventSynchronize(e1);
+                float ms; hipEventElapsedTime(&ms, e0, e1);
+                if (ms < best) best = ms;
+            }
+            printf("lds=%5d mode=%d: %.3f ms  %.0f GB/s\n", lds, mode, best, bytes / best / 1e6);
+        }
+    }
+    if (hipGetLastError() != hipSuccess) printf("HIP error\n");
+    hipFree(buf);
+    return 0;
+}
