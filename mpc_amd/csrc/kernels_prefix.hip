@@ -16,8 +16,6 @@
 //
 // Restates: MPC:665-692 (_cost_function), MPC:249-381 (stage/terminal cost), DYN:101-128 (Euler
 // step), MPC:388-411 (constraint), NUMDIFF:44-72,498-524,584-625 (scipy's forward difference).
-#include <cstdlib>
-
 #include "mpc_device.hpp"
 #include "mpc_kernels.hpp"
 
@@ -37,7 +35,6 @@ struct PrefixArgs {
     double *jac;
     int S;      // scenarios per workgroup
     int items;  // phase-2 lanes per scenario = 6 * ceil(H/2)
-    int debug;
 };
 
 // LDS layout of one scenario (offsets in doubles)
@@ -339,7 +336,7 @@ __global__ __launch_bounds__(128) void prefix_kernel(const mpc_params P, const P
     double acc = 0.0, xv = 0.0, x0v = 0.0, dx = 1.0;
     double p[3] = {0, 0, 0}, o[3] = {0, 0, 0};
     double qc = 0.0, qnp = 0.0, qnb = 0.0;
-    const int iters = (A.debug & 1) ? 0 : H + 3;
+    const int iters = H + 3;
     for (int step = 0; step < iters; ++step) {
         if (!active) continue;
         if (need_init) {
@@ -411,7 +408,7 @@ __global__ __launch_bounds__(128) void prefix_kernel(const mpc_params P, const P
             if (pert < npert) need_init = true; else active = false;
         }
     }
-    if (A.jac == nullptr || (A.debug & 2)) return;
+    if (A.jac == nullptr) return;
     __syncthreads();
 
     // ================= phase 3: dense dc/dx, column-major m x n per scenario ====================
@@ -517,7 +514,6 @@ hipError_t launch_prefix(const mpc_params &P, const double *decay, const mpc_sce
     PrefixArgs A;
     A.decay = decay; A.sc = sc; A.x = x; A.cost = cost; A.grad = grad; A.con = con; A.jac = jac;
     A.S = g.S; A.items = g.items;
-    { const char *e = getenv("MPC_AMD_DEBUG"); A.debug = e ? atoi(e) : 0; }
     const unsigned grid = (unsigned)((sc.count + g.S - 1) / g.S);
     const bool same_dt = P.dt_cost == P.dt_con;
     if (fd) {
