@@ -1,0 +1,57 @@
+"""CPU: host-side glue of the drop-in layer that needs no GPU."""
+import os
+
+import numpy as np
+import pytest
+
+from mpc_amd.params import MpcParams
+from mpc_amd.scenarios import dls_guess, make_scenarios, world_to_base
+from mpc_amd.ur_mpc import KinematicBasePredictor, _pack_base, _unpack_base_traj
+from helpers import host_scenarios, params_for
+from oracle.numpy_ref import NumpyRefMPC, RefParams
+
+
+def test_kinematic_predictor_matches_reference_golden(golden_dir):
+    path = os.path.join(golden_dir, "base_motion.npz")
+    if not os.path.exists(path):
+        pytest.skip("golden not generated")
+    g = np.load(path, allow_pickle=False)
+    H = int(g["H"])
+    pred = KinematicBasePredictor()
+    for t in range(g["base"].shape[0]):
+        b = g["base"][t]
+        bs = {"position": b[0:3], "orientation": b[3:6], "linear_velocity": b[6:9], "angular_velocity": b[9:12]}
+        got = np.stack([_pack_base(e) for e in pred.predict(bs, H, 0.07)])
+        np.testing.assert_array_equal(got, g["kinematic"][t])
+
+
+def test_pack_roundtrip():
+    rng = np.random.default_rng(0)
+    arr = rng.standard_normal((5, 12))
+    back = np.stack([_pack_base(e) for e in _unpack_base_traj(arr)])
+    np.testing.assert_array_equal(back, arr)
+
+
+def test_batched_dls_guess_matches_reference_formula():
+    mp = params_for(3)
+    co, hs = host_scenarios(mp, 5, motion="angular", cfg_id=3)
+    ref = NumpyRefMPC(RefParams(horizon=3))
+    for i in range(5):
+        b = hs.base[i]
+        bs = {"position": b[0:3], "orientation": b[3:6], "linear_velocity": b[6:9], "angular_velocity": b[9:12]}
+        ee = {"position": hs.state0[i, 12:15], "orientation": hs.state0[i, 15:18]}
+        want = ref.dls_guess(hs.Jc[i].reshape(6, 6), bs, ee)
+        np.testing.assert_allclose(hs.u_init[i], want, rtol=1e-9, atol=1e-12)
+
+
+def test_scenarios_are_shard_stable_and_in_bounds():
+    mp = params_for(20)
+    co, full = host_scenarios(mp, 40, motion="linear", cfg_id=2)
+    _, part = host_scenarios(mp, 15, motion="linear", cfg_id=2, first=25)
+    for name in ("x", "state0", "target", "base_traj", "Jc"):
+        np.testing.assert_array_equal(getattr(full, name)[25:], getattr(part, name))
+    lim = np.tile(np.asarray(mp.v_lim), 20)
+    assert np.all(np.abs(full.x) <= lim)
+    # platform family of the reference's simulator: 0.1 Hz, amplitude 0.05-0.30 m on x
+    w = 2 * np.pi * 0.1
+    assert np.all(np.abs(full.base[:, 6]) <= 0.30 * w + 1e-12) and np.all(full.base[:, [1, 2, 7, 8]] == 0)
