@@ -1,0 +1,232 @@
+"""Batched SLSQP: N independent MPC problems advanced in lock-step.
+
+The reference solves one problem per tick with ``scipy.optimize.minimize(method='SLSQP')``
+(ur_mpc.py:188-200).  scipy's driver (``_slsqp_py.py:216-456``) is a reverse-communication loop
+around a Fortran core: the core returns ``mode = 1`` ("give me f and c at x") or ``mode = -1``
+("give me grad f and dc/dx at x") until it is done.  Here every problem keeps its own core state
+on the host, and each round's requests are served by ONE device launch per request kind
+(``mpc_eval`` for the mode-1 problems, ``mpc_eval_fd`` for the mode -1 problems).  The iterates are
+those of scipy's own driver with the reference's options (``ftol=1e-3, maxiter=50, eps=1e-3``),
+because the same core sees the same numbers.
+
+The per-problem quadratic subproblem stays on the host (scipy's compiled core, n = 6H variables,
+m = 12(H+1) inequality rows): solves/s is host-bound, evals/s is not.  The dense dc/dx arrives in
+exactly the memory layout the core wants (column-major m x (n+1) with a zero last column,
+``_slsqp_py.py:509``), so it is one D2H copy into the core's own array.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import List, Optional
+
+import numpy as np
+import torch
+
+from .batch import EvalResult, MpcContext, ScenarioBatch
+
+try:  # private f2py entry point of scipy <= 1.15 (signature checked in tests/test_abi_load.py)
+    from scipy.optimize._slsqp import slsqp as _slsqp_core
+except Exception as exc:  # pragma: no cover
+    _slsqp_core = None
+    _slsqp_import_error = exc
+
+EXIT_MESSAGES = {
+    -1: "Gradient evaluation required (g & a)", 0: "Optimization terminated successfully",
+    1: "Function evaluation required (f & c)", 2: "More equality constraints than independent variables",
+    3: "More than 3*n iterations in LSQ subproblem", 4: "Inequality constraints incompatible",
+    5: "Singular matrix E in LSQ subproblem", 6: "Singular matrix C in LSQ subproblem",
+    7: "Rank-deficient equality constraint subproblem HFTI", 8: "Positive directional derivative for linesearch",
+    9: "Iteration limit reached",
+}
+
+
+class _Problem:
+    """Host-side state of one SLSQP instance (the arrays `_minimize_slsqp` allocates, _slsqp_py.py:343-409)."""
+
+    __slots__ = ("x", "fx", "c", "g", "a", "w", "jw", "mode", "majiter", "acc", "scal", "ints", "done")
+
+    def __init__(self, x0, n, m, acc, maxiter, a_view):
+        n1 = n + 1
+        meq = 0
+        mineq = m - meq + n1 + n1
+        len_w = ((3 * n1 + m) * (n1 + 1) + (n1 - meq + 1) * (mineq + 2) + 2 * mineq + (n1 + mineq) * (n1 - meq)
+                 + 2 * meq + n1 + ((n + 1) * n) // 2 + 2 * m + 3 * n + 3 * n1 + 1)
+        self.x = x0
+        self.fx = 0.0
+        self.c = np.zeros(m)
+        self.g = np.zeros(n1)
+        self.a = a_view                      # (m, n+1) Fortran-ordered view into the batch array
+        self.w = np.zeros(len_w)
+        self.jw = np.zeros(mineq)
+        self.mode = np.array(0, int)
+        self.majiter = np.array(maxiter - 1, int)
+        self.acc = np.array(acc, float)
+        self.scal = [np.array(0, float) for _ in range(9)]   # alpha, f0, gs, h1..h4, t, t0
+        self.scal.append(np.array(0, float))                 # tol
+        self.ints = [np.array(0, int) for _ in range(8)]     # iexact, incons, ireset, itermx, line, n1, n2, n3
+        self.done = False
+
+
+@dataclass
+class BatchSolveResult:
+    x: np.ndarray          # [N, n]
+    fun: np.ndarray        # [N]
+    nit: np.ndarray        # [N]
+    status: np.ndarray     # [N] SLSQP exit mode, 0 = success
+    rounds: int            # lock-step rounds = device launches of each kind at most
+    n_eval: int            # scenario-evals served by mpc_eval   (f, c)
+    n_eval_fd: int         # scenario-evals served by mpc_eval_fd (f, c, grad, dc/dx)
+
+    @property
+    def success(self):
+        return self.status == 0
+
+
+class BatchedSLSQP:
+    def __init__(self, ctx: MpcContext):
+        if _slsqp_core is None:
+            raise ImportError(f"scipy.optimize._slsqp.slsqp is not importable: {_slsqp_import_error}")
+        self.ctx = ctx
+        p = ctx.params
+        self.n, self.m = p.n, p.m
+        self.lb = np.array([b[0] for b in p.bounds()])
+        self.ub = np.array([b[1] for b in p.bounds()])
+
+    def _to_dev(self, a):
+        return torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float64).to(self.ctx.device)
+
+    def solve(self, sc: ScenarioBatch, x0: np.ndarray) -> BatchSolveResult:
+        ctx, n, m = self.ctx, self.n, self.m
+        N = sc.count
+        if N > ctx.max_scenarios:
+            raise ValueError("batch larger than the context")
+        X = np.clip(np.array(x0, dtype=np.float64).reshape(N, n), self.lb, self.ub)   # _slsqp_py.py:268
+        A = np.zeros((N, n + 1, m))          # A[i].T is the core's a(la, n+1), column-major
+        probs: List[_Problem] = [_Problem(X[i], n, m, ctx.params.ftol, ctx.params.maxiter, A[i].T)
+                                 for i in range(N)]
+        xl, xu = self.lb.copy(), self.ub.copy()
+        n_eval = n_eval_fd = rounds = 0
+
+        def serve(idx: np.ndarray, need_grad: bool):
+            """One device launch for the problems in idx; x is clipped like _clip_x_for_func."""
+            sub = _gather(sc, idx, ctx.device)
+            xd = self._to_dev(np.clip(X[idx], self.lb, self.ub))
+            if need_grad:
+                r = ctx.eval_fd(sub, xd)
+                g = r.grad.cpu().numpy()
+                jac = r.con_jac.cpu().numpy()
+                for k, i in enumerate(idx):
+                    probs[i].g[:n] = g[k]
+                    probs[i].g[n] = 0.0
+                    A[i, :n, :] = jac[k]
+                return r
+            return ctx.eval(sub, xd)
+
+        # mode 0 on entry: f, g, c, a at the start point (_slsqp_py.py:419-425)
+        allidx = np.arange(N)
+        r = serve(allidx, True)
+        f0 = r.cost.cpu().numpy()
+        c0 = r.con.cpu().numpy()
+        for i in allidx:
+            probs[i].fx = float(f0[i])
+            probs[i].c[:] = c0[i]
+        n_eval_fd += N
+        active = list(range(N))
+        while active:
+            rounds += 1
+            want_f, want_g = [], []
+            for i in active:
+                p = probs[i]
+                s = p.scal
+                it = p.ints
+                _slsqp_core(m, 0, p.x, xl, xu, p.fx, p.c, p.g, p.a, p.acc, p.majiter, p.mode, p.w, p.jw,
+                            s[0], s[1], s[2], s[3], s[4], s[5], s[6], s[7], s[8], s[9],
+                            it[0], it[1], it[2], it[3], it[4], it[5], it[6], it[7])
+                md = int(p.mode)
+                if md == 1:
+                    want_f.append(i)
+                elif md == -1:
+                    want_g.append(i)
+                else:
+                    p.done = True
+            if want_f:
+                idx = np.array(want_f)
+                r = serve(idx, False)
+                f = r.cost.cpu().numpy()
+                c = r.con.cpu().numpy()
+                for k, i in enumerate(idx):
+                    probs[i].fx = float(f[k])
+                    probs[i].c[:] = c[k]
+                n_eval += len(idx)
+            if want_g:
+                serve(np.array(want_g), True)
+                n_eval_fd += len(want_g)
+            active = [i for i in active if not probs[i].done]
+        return BatchSolveResult(
+            x=X, fun=np.array([p.fx for p in probs]), nit=np.array([int(p.majiter) for p in probs]),
+            status=np.array([int(p.mode) for p in probs]), rounds=rounds, n_eval=n_eval, n_eval_fd=n_eval_fd)
+
+
+def _gather(sc: ScenarioBatch, idx: np.ndarray, device) -> ScenarioBatch:
+    """Rows idx of a device-resident batch (contiguous copy; a full ascending range is returned as is)."""
+    if len(idx) == sc.count and np.array_equal(idx, np.arange(sc.count)):
+        return sc
+    t = torch.as_tensor(idx, dtype=torch.long, device=device)
+    f = lambda a: None if a is None else a.index_select(0, t).contiguous()
+    return ScenarioBatch(f(sc.state0), f(sc.target), f(sc.base_traj), f(sc.Jc), f(sc.u_prev), f(sc.has_prev))
+
+
+class BatchedMPC:
+    """N controllers ticking together: the batched equivalent of ``URMPC.compute_control``
+    (ur_mpc.py:83-247) including the early exit, the DLS start, warm start, output EMA and clip."""
+
+    def __init__(self, ctx: MpcContext):
+        self.ctx = ctx
+        self.solver = BatchedSLSQP(ctx)
+        self.previous_solution: Optional[np.ndarray] = None   # [N, n], NaN rows = no solution yet
+        self.previous_control: Optional[np.ndarray] = None    # [N, 6], NaN rows = attribute absent
+        self.last: Optional[BatchSolveResult] = None
+
+    def compute_control(self, q: np.ndarray, ee_pose: np.ndarray, target: np.ndarray, base: np.ndarray) -> np.ndarray:
+        """q [N,6], ee_pose [N,6] = [pos, rpy], target [N,6], base [N,12] -> controls [N,6]."""
+        from .scenarios import dls_guess
+
+        ctx, p = self.ctx, self.ctx.params
+        N, n, H = q.shape[0], p.n, p.horizon
+        if self.previous_solution is None:
+            self.previous_solution = np.full((N, n), np.nan)
+            self.previous_control = np.full((N, 6), np.nan)
+        out = np.zeros((N, 6))
+        active = ~((np.linalg.norm(base[:, 6:9], axis=1) < 0.01) & (np.linalg.norm(base[:, 9:12], axis=1) < 0.01))
+        idx = np.nonzero(active)[0]
+        if len(idx) == 0:
+            return out
+        dev = ctx.device
+        up = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float64).to(dev)
+        Jc = ctx.jacobian(up(q[idx])).cpu().numpy().reshape(-1, 36)
+        bt = ctx.predict_base_dynamic(up(base[idx]))
+        if not p.use_dynamic_model:
+            raise NotImplementedError("the batched tick uses the dynamic platform model (controller_params.yaml:30)")
+        u_init = dls_guess(Jc, base[idx], ee_pose[idx, :3])
+        prev_sol = self.previous_solution[idx]
+        have_sol = ~np.isnan(prev_sol[:, 0])
+        x0 = np.tile(u_init, (1, H))
+        if have_sol.any():                                             # ur_mpc.py:178-181
+            rolled = np.roll(prev_sol[have_sol], -6, axis=1)
+            rolled[:, -6:] = u_init[have_sol]
+            x0[have_sol] = rolled
+        prev_u = self.previous_control[idx]
+        have_u = ~np.isnan(prev_u[:, 0])
+        state0 = np.concatenate([q[idx], np.zeros((len(idx), 6)), ee_pose[idx]], axis=1)
+        sc = ScenarioBatch(up(state0), up(target[idx]), bt, up(Jc), up(np.nan_to_num(prev_u)),
+                           torch.as_tensor(have_u.astype(np.uint8)).to(dev))
+        res = self.solver.solve(sc, x0)
+        self.last = res
+        ok = res.success
+        u = res.x[:, :6].copy()
+        u[have_u & ok] = 0.5 * u[have_u & ok] + 0.5 * prev_u[have_u & ok]      # ur_mpc.py:209-212
+        ctrl = np.where(ok[:, None], np.clip(u, -0.5, 0.5), u_init)            # ur_mpc.py:234-241
+        self.previous_control[idx[ok]] = u[ok]
+        self.previous_solution[idx[ok]] = res.x[ok]
+        out[idx] = ctrl
+        return out

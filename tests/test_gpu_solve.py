@@ -65,3 +65,52 @@ def test_interface_matches_reference_class():
     want = np.concatenate([np.concatenate([np.minimum(s[:6] + 2 * np.pi, 2 * np.pi - s[:6]), lim - np.abs(s[6:12])])
                            for s in traj])
     np.testing.assert_allclose(c, want, rtol=0, atol=1e-13)
+
+
+@pytest.mark.parametrize("H", [1, 3, 20])
+def test_batched_mpc_matches_reference(golden_dir, H):
+    """All golden scenarios of one horizon advance together through the lock-step SLSQP driver."""
+    from mpc_amd.batch import MpcContext
+    from mpc_amd.solver import BatchedMPC
+
+    path = os.path.join(golden_dir, f"solve_H{H}.npz")
+    if not os.path.exists(path):
+        pytest.skip("golden not generated")
+    g = np.load(path, allow_pickle=False)
+    N = g["q0"].shape[0]
+    ctx = MpcContext(MpcParams.reference_yaml_defaults(horizon=H), max_scenarios=N, device=0)
+    bm = BatchedMPC(ctx)
+    for tick in range(g["control"].shape[1]):
+        u = bm.compute_control(g["q0"], g["ee"], g["target"], g["base"])
+        assert bm.last.success.all()
+        np.testing.assert_allclose(bm.previous_solution, g["solution"][:, tick], rtol=0, atol=SOL_ATOL)
+        np.testing.assert_allclose(u, g["control"][:, tick], rtol=0, atol=SOL_ATOL)
+
+
+def test_batched_solver_equals_single_scenario_driver():
+    """64 seeded scenarios: the lock-step driver and scipy.minimize with device callbacks agree."""
+    from helpers import host_scenarios
+    from mpc_amd.batch import MpcContext
+    from mpc_amd.scenarios import to_device
+    from mpc_amd.solver import BatchedSLSQP
+    from scipy.optimize import minimize
+
+    mp = MpcParams.reference_yaml_defaults(horizon=3)
+    _, hs = host_scenarios(mp, 64, motion="angular", cfg_id=3)
+    ctx = MpcContext(mp, 64, 0)
+    sc, _ = to_device(ctx, hs)
+    res = BatchedSLSQP(ctx).solve(sc, hs.x)
+    assert res.success.sum() >= 60
+    one = MpcContext(mp, 1, 0)
+    for i in (0, 17, 63):
+        sci = sc.slice(i, i + 1)
+
+        def ev(x):
+            r = one.eval_fd(sci, torch.as_tensor(np.clip(x, -np.tile(mp.v_lim, 3), np.tile(mp.v_lim, 3)).reshape(1, -1)).to(one.device))
+            return float(r.cost.cpu()[0]), r.grad[0].cpu().numpy(), r.con[0].cpu().numpy(), r.con_jac[0].cpu().numpy().T
+
+        ref = minimize(lambda x: ev(x)[0], hs.x[i], jac=lambda x: ev(x)[1], method="SLSQP", bounds=mp.bounds(),
+                       constraints=[{"type": "ineq", "fun": lambda x: ev(x)[2], "jac": lambda x: ev(x)[3]}],
+                       options={"ftol": 1e-3, "maxiter": 50})
+        np.testing.assert_allclose(res.x[i], ref.x, rtol=0, atol=1e-12)
+        assert res.nit[i] == ref.nit and res.status[i] == ref.status
