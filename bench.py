@@ -79,6 +79,27 @@ def cpu_baseline(mp: MpcParams, hs, budget_s: float = 12.0):
     }
 
 
+def solve_rate(ctx, mp, count):
+    """MPC solves/s on a bounded sample (BASELINE.json's second metric): full SLSQP solves of
+    angular-motion scenarios (configs[2] shape) through the lock-step driver.  The quadratic
+    subproblems run in scipy's compiled core on ONE host core, so this rate is host-bound."""
+    from mpc_amd.solver import BatchedMPC
+
+    if count <= 0:
+        return None
+    hs = make_scenarios(mp, DeviceKinematics(ctx), count, motion="angular", cfg_id=3, goal_jitter=0.0)
+    bm = BatchedMPC(ctx)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    bm.compute_control(hs.q0, hs.state0[:, 12:18], hs.target, hs.base)
+    dt = time.perf_counter() - t0
+    r = bm.last
+    return {"value": int(hs.active.sum()) / dt, "unit": "solves/s", "sample": f"{count} angular-motion scenarios, H={mp.horizon}, "
+            f"one tick each, {int(r.success.sum())} converged, {r.rounds} lock-step rounds, "
+            f"{r.n_eval_fd} eval_fd + {r.n_eval} eval scenario-evals on the GPU, SLSQP core on 1 host core",
+            "host_bound": True, "seconds": dt, "mean_iterations": float(r.nit.mean())}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -89,6 +110,7 @@ def main():
     ap.add_argument("--motion", default="linear", choices=["linear", "angular"])
     ap.add_argument("--algo", type=int, default=_ffi.ALGO_AUTO)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--solve-sample", type=int, default=96, help="scenarios in the bounded solves/s sample")
     ap.add_argument("--only-main", action="store_true",
                     help="run only the timed loop (profiling: every dispatch of the kernel is the benchmark's)")
     args = ap.parse_args()
@@ -170,25 +192,24 @@ def main():
                          "fp64_valu": {"achieved_tflops_algorithmic": aflops * S / (kernel_ms * 1e-3) / 1e12,
                                        "peak_tflops": FP64_VALU_PEAK_TF, "algorithmic_flops_per_eval": aflops}},
         }
-        if args.only_main:
-            print(json.dumps(line), flush=True)
-            return
         # compute-side view: same evals without the dense dc/dx stream (gradient + constraints only)
+        extras = not args.only_main
         out2 = EvalResult(out.cost, out.grad, out.con, None)
-        for _ in range(2):
+        for _ in range(2 if extras else 0):
             ctx.eval_fd(sc, x, want_jac=False, out=out2)
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        for _ in range(args.steps):
+        for _ in range(args.steps if extras else 0):
             ctx.eval_fd(sc, x, want_jac=False, out=out2)
         e1.record()
         torch.cuda.synchronize()
         ms_nj = e0.elapsed_time(e1) / args.steps
-        line["no_dense_jacobian"] = {"evals_per_s": S / (ms_nj * 1e-3), "kernel_ms": ms_nj,
+        if extras:
+            line["no_dense_jacobian"] = {"evals_per_s": S / (ms_nj * 1e-3), "kernel_ms": ms_nj,
                                      "fp64_tflops_algorithmic": aflops * S / (ms_nj * 1e-3) / 1e12,
                                      "frac_of_fp64_valu_peak": aflops * S / (ms_nj * 1e-3) / 1e12 / FP64_VALU_PEAK_TF}
-        if S > 4096:   # configs[1] of BASELINE.json: 4,096 scenarios on one GPU
+        if extras and S > 4096:   # configs[1] of BASELINE.json: 4,096 scenarios on one GPU
             sc4, x4 = sc.slice(0, 4096), x[:4096]
             o4 = EvalResult(out.cost[:4096], out.grad[:4096], out.con[:4096], out.con_jac[:4096])
             for _ in range(3):
@@ -200,7 +221,9 @@ def main():
             e1.record()
             torch.cuda.synchronize()
             line["evals_per_s_4096_scenarios"] = 4096 / (e0.elapsed_time(e1) / args.steps * 1e-3)
-        if not args.no_cpu_baseline and world == 1:
+        if extras and world == 1:
+            line["solves"] = solve_rate(ctx, mp, args.solve_sample)
+        if extras and not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(mp, hs)
             line["speedup_vs_cpu_core"] = value / world / line["cpu_baseline"]["value"]
         print(json.dumps(line), flush=True)
