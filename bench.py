@@ -79,6 +79,21 @@ def cpu_baseline(mp: MpcParams, hs, budget_s: float = 12.0):
     }
 
 
+def measured_traffic(H, S, algo):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, the
+    gfx950 correction of MI355X_MICROARCH.md), if a measurement of this exact configuration exists."""
+    import glob
+
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "traffic.json")), reverse=True):
+        try:
+            t = json.load(open(path))
+        except Exception:
+            continue
+        if t.get("horizon") == H and t.get("scenarios") == S and t.get("algo") == algo:
+            return float(t["traffic_bytes_per_launch"]), os.path.relpath(path, ROOT)
+    return None, None
+
+
 def solve_rate(ctx, mp, count):
     """MPC solves/s on a bounded sample (BASELINE.json's second metric): full SLSQP solves of
     angular-motion scenarios (configs[2] shape) through the lock-step driver.  The quadratic
@@ -176,6 +191,8 @@ def main():
         value = total_evals / elapsed
         abytes, aflops = algorithmic_bytes(H), algorithmic_flops(H)
         achieved = abytes * S / (kernel_ms * 1e-3) / 1e9
+        algo_name = "prefix" if ctx.params.algo != _ffi.ALGO_ROLLOUT else "rollout"
+        traffic, traffic_src = measured_traffic(H, S, algo_name)
         line = {
             "metric": "objective+gradient evals/sec (f, c, FD grad f, dense FD dc/dx per scenario)",
             "value": value, "unit": "evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -184,10 +201,11 @@ def main():
             "config": {"workload": f"{args.motion}-platform-motion scenarios, H={H}, objective+FD gradient+dense FD "
                                    f"constraint Jacobian, {S} scenarios per GPU resident in HBM (north_star target size)",
                        "horizon": H, "scenarios_per_gpu": S, "n_vars": mp.n, "n_constraints": mp.m,
-                       "algo": "prefix" if ctx.params.algo != _ffi.ALGO_ROLLOUT else "rollout",
+                       "algo": algo_name,
                        "parallelism": f"scenario-dp{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                         "algorithmic_bytes_per_launch": abytes * S,
                          "kernel_ms": kernel_ms, "algorithmic_bytes_per_eval": abytes,
                          "fp64_valu": {"achieved_tflops_algorithmic": aflops * S / (kernel_ms * 1e-3) / 1e12,
                                        "peak_tflops": FP64_VALU_PEAK_TF, "algorithmic_flops_per_eval": aflops}},
