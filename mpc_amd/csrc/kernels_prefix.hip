@@ -459,7 +459,7 @@ __global__ __launch_bounds__(128) void prefix_kernel(const mpc_params P, const P
                     if (ps < npass && live[ps]) {
                         const bool mine = gp[ps] == (aa >> 1);
                         const v2d v = (aa & 1) ? v2d{0.0, mine ? val[ps].y : 0.0} : v2d{mine ? val[ps].x : 0.0, 0.0};
-                        __builtin_nontemporal_store(v, reinterpret_cast<v2d *>(col + 128 * ps));
+                        *reinterpret_cast<v2d *>(col + 128 * ps) = v;  // plain store: nt measured 15 % slower (tools/store_bw.hip)
                     }
                 }
             }

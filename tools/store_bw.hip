@@ -12,7 +12,7 @@ constexpr int BLK = 120 * 252;  // doubles per block
 // mode 0: flat aligned 1 KB stores; mode 1: 252-double columns as 64+62 lane stores;
 // mode 2: flat, but consecutive blocks of the grid interleave chunks (grid-stride over the whole buffer)
 template <int MODE>
-__global__ __launch_bounds__(64) void k(double *out, int nblocks, int lds_pad)
+__global__ __launch_bounds__(256) void k(double *out, int nblocks, int lds_pad)
 {
     extern __shared__ double pad[];
     const int lane = threadIdx.x;
@@ -30,6 +30,28 @@ __global__ __launch_bounds__(64) void k(double *out, int nblocks, int lds_pad)
             *reinterpret_cast<v2d *>(dst + 2 * lane) = z;
             if (lane < 62) *reinterpret_cast<v2d *>(dst + 128 + 2 * lane) = z;
         }
+    } else if (MODE == 3 || MODE == 4) {
+        // 256-thread workgroup streams 4 consecutive blocks; all 4 waves work on the same block:
+        // MODE 3: wave w takes columns [30w, 30w+30); MODE 4: wave w takes columns c = w (mod 4)
+        const int wave = threadIdx.x >> 6, ln = threadIdx.x & 63;
+        const v2d zz = {0.0, (double)ln};
+        for (int b = 0; b < 4; ++b) {
+            double *base = out + ((size_t)blockIdx.x * 4 + b) * BLK;   // blockIdx.x < nblocks/4
+            for (int i = 0; i < 30; ++i) {
+                const int col = (MODE == 3) ? 30 * wave + i : 4 * i + wave;   // < 120
+                double *dst = base + col * 252;
+                *reinterpret_cast<v2d *>(dst + 2 * ln) = zz;
+                if (ln < 62) *reinterpret_cast<v2d *>(dst + 128 + 2 * ln) = zz;
+            }
+        }
+    } else if (MODE == 5) {
+        // like MODE 1 with non-temporal stores
+        double *base = out + (size_t)blockIdx.x * BLK;
+        for (int col = 0; col < 120; ++col) {
+            double *dst = base + col * 252;
+            __builtin_nontemporal_store(z, reinterpret_cast<v2d *>(dst + 2 * lane));
+            if (lane < 62) __builtin_nontemporal_store(z, reinterpret_cast<v2d *>(dst + 128 + 2 * lane));
+        }
     } else {
         const size_t total = (size_t)nblocks * BLK / 2;  // v2d elements
         v2d *o = reinterpret_cast<v2d *>(out);
@@ -45,14 +67,17 @@ int main(int argc, char **argv)
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
     const size_t bytes = sizeof(double) * (size_t)nblocks * BLK;
-    for (int lds : {0, 21 * 1024, 40 * 1024}) {
-        for (int mode = 0; mode < 3; ++mode) {
+    for (int lds : {0, 20 * 1024}) {
+        for (int mode = 0; mode < 6; ++mode) {
             float best = 1e9;
             for (int rep = 0; rep < 4; ++rep) {
                 hipEventRecord(e0);
                 if (mode == 0) hipLaunchKernelGGL(k<0>, dim3(nblocks), dim3(64), lds, 0, buf, nblocks, 0);
                 if (mode == 1) hipLaunchKernelGGL(k<1>, dim3(nblocks), dim3(64), lds, 0, buf, nblocks, 0);
                 if (mode == 2) hipLaunchKernelGGL(k<2>, dim3(256 * 8), dim3(64), lds, 0, buf, nblocks, 0);
+                if (mode == 3) hipLaunchKernelGGL(k<3>, dim3(nblocks / 4), dim3(256), 3 * lds, 0, buf, nblocks, 0);
+                if (mode == 4) hipLaunchKernelGGL(k<4>, dim3(nblocks / 4), dim3(256), 3 * lds, 0, buf, nblocks, 0);
+                if (mode == 5) hipLaunchKernelGGL(k<5>, dim3(nblocks), dim3(64), lds, 0, buf, nblocks, 0);
                 hipEventRecord(e1);
                 hipEventSynchronize(e1);
                 float ms; hipEventElapsedTime(&ms, e0, e1);
