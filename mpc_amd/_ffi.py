@@ -6,7 +6,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmpc_amd.so")
+LIB_PATH = os.environ.get("MPC_AMD_LIB") or os.path.join(_HERE, "libmpc_amd.so")  # override: A/B builds
 
 MPC_OK = 0
 ALGO_AUTO, ALGO_ROLLOUT, ALGO_PREFIX = 0, 1, 2

@@ -146,6 +146,10 @@ __device__ __forceinline__ void ur_twist(const mpc_params &P, const double (&sn)
 // Stage cost L_k (stage = true, MPC:249-328) or terminal cost (MPC:330-381) with one code path:
 // the terminal form is the stage form with decay -> (terminal_factor, 1), no control terms, and
 // V = J(q_H) dq_H instead of Jc u_k.  Adding the three +0.0 terms leaves the value unchanged.
+// Products and sums inside one term are fused (a few ulp from the reference's unfused order);
+// the order in which the seven terms are added is the reference's.
+__device__ __forceinline__ double sumsq3f(double a, double b, double c) { return fma(c, c, fma(b, b, a * a)); }
+
 __device__ __forceinline__ double unit_cost(const mpc_params &P, bool stage, const double (&V)[6],
                                             const double (&u)[6], const double (&p)[3], const double (&o)[3],
                                             const double *b, double cy, double sy, const double *tgt, double dk,
@@ -153,31 +157,37 @@ __device__ __forceinline__ double unit_cost(const mpc_params &P, bool stage, con
 {
     const double r0 = p[0] - b[0], r1 = p[1] - b[1], r2 = p[2] - b[2];
     const double O0 = b[9], O1 = b[10], O2 = b[11];
-    const double x0 = O1 * r2 - O2 * r1;
-    const double x1 = O2 * r0 - O0 * r2;
-    const double x2 = O0 * r1 - O1 * r0;
-    const double w0 = -(b[6] + x0), w1 = -(b[7] + x1), w2 = -(b[8] + x2);
-    const double a0 = -O0, a1 = -O1, a2 = -O2;
-    const double tl0 = (cy * w0 + sy * w1) + 0.0 * w2;
-    const double tl1 = (-sy * w0 + cy * w1) + 0.0 * w2;
-    const double tl2 = (0.0 * w0 + 0.0 * w1) + 1.0 * w2;
-    const double ta0 = (cy * a0 + sy * a1) + 0.0 * a2;
-    const double ta1 = (-sy * a0 + cy * a1) + 0.0 * a2;
-    const double ta2 = (0.0 * a0 + 0.0 * a1) + 1.0 * a2;
+    // -(V + Omega x r), -(Omega), rotated by R(psi) = [[c,s,0],[-s,c,0],[0,0,1]] (MPC:270-283,714-720)
+    const double w0 = -(b[6] + fma(O1, r2, -(O2 * r1)));
+    const double w1 = -(b[7] + fma(O2, r0, -(O0 * r2)));
+    const double w2 = -(b[8] + fma(O0, r1, -(O1 * r0)));
+    const double tl0 = fma(sy, w1, cy * w0), tl1 = fma(cy, w1, -(sy * w0)), tl2 = w2;
+    const double ta0 = -fma(sy, O1, cy * O0), ta1 = fma(sy, O0, -(cy * O1)), ta2 = -O2;
     const double fv = stage ? dk : P.terminal_factor;
     const double fp = stage ? dk : 1.0;
-    const double c_lin = P.w_linear * fv * sumsq3(V[0] - tl0, V[1] - tl1, V[2] - tl2);
-    const double c_ang = P.w_angular * fv * sumsq3(V[3] - ta0, V[4] - ta1, V[5] - ta2);
-    const double c_pos = P.w_position * fp * sumsq3(p[0] - tgt[0], p[1] - tgt[1], p[2] - tgt[2]);
-    const double c_ori = P.w_orientation * fp * sumsq3(o[0] - tgt[3], o[1] - tgt[4], o[2] - tgt[5]);
-    const double uu = sumsq6(u);
-    const double c_ctl = stage ? P.w_control * uu : 0.0;
-    double du[6];
+    const double c_lin = P.w_linear * fv * sumsq3f(V[0] - tl0, V[1] - tl1, V[2] - tl2);
+    const double c_ang = P.w_angular * fv * sumsq3f(V[3] - ta0, V[4] - ta1, V[5] - ta2);
+    const double c_pos = P.w_position * fp * sumsq3f(p[0] - tgt[0], p[1] - tgt[1], p[2] - tgt[2]);
+    const double c_ori = P.w_orientation * fp * sumsq3f(o[0] - tgt[3], o[1] - tgt[4], o[2] - tgt[5]);
+    double uu = u[0] * u[0], dd = (u[0] - up[0]) * (u[0] - up[0]);
 #pragma unroll
-    for (int j = 0; j < 6; ++j) du[j] = u[j] - up[j];
-    const double c_damp = damp ? P.w_damping * sumsq6(du) : 0.0;
+    for (int j = 1; j < 6; ++j) {
+        uu = fma(u[j], u[j], uu);
+        const double d = u[j] - up[j];
+        dd = fma(d, d, dd);
+    }
+    const double c_ctl = stage ? P.w_control * uu : 0.0;
+    const double c_damp = damp ? P.w_damping * dd : 0.0;
     const double c_smooth = smooth ? P.w_smooth * uu : 0.0;
     return (((((c_lin + c_ang) + c_pos) + c_ori) + c_ctl) + c_damp) + c_smooth;
+}
+
+// num / dx from a reciprocal computed once per perturbation, with one residual correction step:
+// equal to the correctly rounded quotient except for rare last-place ties.
+__device__ __forceinline__ double quot(double num, double dx, double rdx)
+{
+    const double q = num * rdx;
+    return fma(fma(-dx, q, num), rdx, q);
 }
 
 __device__ __forceinline__ double pick6(const double (&a)[6], int j)
@@ -333,7 +343,7 @@ __global__ __launch_bounds__(128) void prefix_kernel(const mpc_params P, const P
 
     bool active = act2, need_init = true;
     int pert = 0, j = 0, k = 0, var = 0, tri_j = 0;
-    double acc = 0.0, xv = 0.0, x0v = 0.0, dx = 1.0;
+    double acc = 0.0, xv = 0.0, x0v = 0.0, dx = 1.0, rdx = 1.0;
     double p[3] = {0, 0, 0}, o[3] = {0, 0, 0};
     double qc = 0.0, qnp = 0.0, qnb = 0.0;
     const int iters = H + 3;
@@ -345,6 +355,7 @@ __global__ __launch_bounds__(128) void prefix_kernel(const mpc_params P, const P
             x0v = S2[Y.xs + var];
             xv = x0v + fd_step(x0v, -lim, lim, P.fd_eps);   // NUMDIFF:594
             dx = xv - x0v;                                   // NUMDIFF:596
+            rdx = 1.0 / dx;
             k = j;
             acc = S2[Y.Cp + j];
 #pragma unroll
@@ -399,11 +410,11 @@ __global__ __launch_bounds__(128) void prefix_kernel(const mpc_params P, const P
             }
             // column `var` of dc/dx, rows of state k+1 (the other rows of the column are +-0)
             const double c1 = fmin(qnp - qlo, qhi - qnp), c0 = fmin(qnb - qlo, qhi - qnb);
-            S2[Y.jpos + 6 * (tri_j + k + 1) + a] = (c1 - c0) / dx;
-            if (k == j) S2[Y.jvel + var] = ((lim - fabs(xv)) - (lim - fabs(x0v))) / dx;
+            S2[Y.jpos + 6 * (tri_j + k + 1) + a] = quot(c1 - c0, dx, rdx);
+            if (k == j) S2[Y.jvel + var] = quot((lim - fabs(xv)) - (lim - fabs(x0v)), dx, rdx);
             k = k + 1;
         } else {
-            if (A.grad != nullptr) A.grad[(size_t)(s0 + ls2) * n + var] = (acc - f0) / dx;  // NUMDIFF:619
+            if (A.grad != nullptr) A.grad[(size_t)(s0 + ls2) * n + var] = quot(acc - f0, dx, rdx);  // NUMDIFF:619
             pert = pert + 1;
             if (pert < npert) need_init = true; else active = false;
         }

@@ -44,6 +44,19 @@ __global__ __launch_bounds__(256) void k(double *out, int nblocks, int lds_pad)
                 if (ln < 62) *reinterpret_cast<v2d *>(dst + 128 + 2 * ln) = zz;
             }
         }
+    } else if (MODE == 6 || MODE == 7) {
+        // torch-fill-like: 256-thread block writes one contiguous 16 KB chunk (4 x 16 B per thread);
+        // MODE 7: 64 KB chunk (16 x 16 B per thread)
+        constexpr int U = (MODE == 6) ? 4 : 16;
+        const size_t total = (size_t)nblocks * BLK / 2;                 // v2d elements
+        v2d *o = reinterpret_cast<v2d *>(out);
+        const size_t base = (size_t)blockIdx.x * 256 * U;
+        const v2d zz = {0.0, 1.0};
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const size_t i = base + (size_t)u * 256 + threadIdx.x;
+            if (i < total) o[i] = zz;
+        }
     } else if (MODE == 5) {
         // like MODE 1 with non-temporal stores
         double *base = out + (size_t)blockIdx.x * BLK;
@@ -68,7 +81,7 @@ int main(int argc, char **argv)
     hipEventCreate(&e0); hipEventCreate(&e1);
     const size_t bytes = sizeof(double) * (size_t)nblocks * BLK;
     for (int lds : {0, 20 * 1024}) {
-        for (int mode = 0; mode < 6; ++mode) {
+        for (int mode = 0; mode < 8; ++mode) {
             float best = 1e9;
             for (int rep = 0; rep < 4; ++rep) {
                 hipEventRecord(e0);
@@ -77,6 +90,8 @@ int main(int argc, char **argv)
                 if (mode == 2) hipLaunchKernelGGL(k<2>, dim3(256 * 8), dim3(64), lds, 0, buf, nblocks, 0);
                 if (mode == 3) hipLaunchKernelGGL(k<3>, dim3(nblocks / 4), dim3(256), 3 * lds, 0, buf, nblocks, 0);
                 if (mode == 4) hipLaunchKernelGGL(k<4>, dim3(nblocks / 4), dim3(256), 3 * lds, 0, buf, nblocks, 0);
+                if (mode == 6) hipLaunchKernelGGL(k<6>, dim3((unsigned)(((size_t)nblocks * BLK / 2 + 1023) / 1024)), dim3(256), 0, 0, buf, nblocks, 0);
+                if (mode == 7) hipLaunchKernelGGL(k<7>, dim3((unsigned)(((size_t)nblocks * BLK / 2 + 4095) / 4096)), dim3(256), 0, 0, buf, nblocks, 0);
                 if (mode == 5) hipLaunchKernelGGL(k<5>, dim3(nblocks), dim3(64), lds, 0, buf, nblocks, 0);
                 hipEventRecord(e1);
                 hipEventSynchronize(e1);
