@@ -23,7 +23,8 @@ namespace {
 
 using namespace mpcdev;
 
-constexpr int kMaxLdsBytes = 64 * 1024;
+constexpr int kMaxLdsBytes = 64 * 1024;    // fused mode: keeps >= 2 workgroups per CU
+constexpr int kMaxLdsLarge = 160 * 1024;   // compact mode: one workgroup may take the whole CU
 
 struct PrefixArgs {
     const double *decay;
@@ -33,16 +34,24 @@ struct PrefixArgs {
     double *grad;
     double *con;
     double *jac;
-    int S;      // scenarios per workgroup
-    int items;  // phase-2 lanes per scenario = 6 * ceil(H/2)
+    double *compact;  // MODE 2: per scenario [6H velocity quotients][3H(H+1) position quotients]
+    int cstride;      // doubles per scenario in `compact`
+    int S;            // scenarios per workgroup
+    int items;        // phase-2 lanes per scenario = 6 * ceil(H/2)
 };
+
+// How the forward-difference work is organised:
+//   kEval    f and c only (phase 1)
+//   kFused   FD, the non-zeros of dc/dx staged in LDS, dense dc/dx written by the same workgroup
+//   kCompact FD for long horizons: the non-zeros go to a global workspace, expand_kernel writes dc/dx
+enum Mode { kEval = 0, kFused = 1, kCompact = 2 };
 
 // LDS layout of one scenario (offsets in doubles)
 struct Layout {
     int xs, bt, ys, st0, tgt, Jc, up, scs, po, qs, qn, Cp, vv, tb, lb, jvel, jpos, total;
 };
 
-__host__ __device__ inline Layout make_layout(int H, bool fd, bool same_dt)
+__host__ __device__ inline Layout make_layout(int H, int mode, bool same_dt)
 {
     Layout Y;
     int o = 0;
@@ -62,7 +71,7 @@ __host__ __device__ inline Layout make_layout(int H, bool fd, bool same_dt)
     Y.tb = o;                       // phase-1 scratch: Euler increments [6H] + step costs [H+1]
     Y.lb = o + 6 * H;
     const int scratch = 7 * H + 1;
-    if (fd) {
+    if (mode == kFused) {
         o += o & 1;                 // 16-byte alignment of the two arrays phase 3 reads as pairs
         Y.jvel = o; o += 6 * H;     // d(vel row of state j+1)/d u_j[a], [j][a]
         Y.jpos = o;                 // d(pos row of state k)/d u_j[a], k > j, packed [tri(j,k)][a]
@@ -198,13 +207,14 @@ __device__ __forceinline__ double pick6(const double (&a)[6], int j)
     return v;
 }
 
-template <bool FD, bool SAME_DT>
-__global__ __launch_bounds__(128) void prefix_kernel(const mpc_params P, const PrefixArgs A)
+template <int MODE, bool SAME_DT, int MAXT>
+__global__ __launch_bounds__(MAXT) void prefix_kernel(const mpc_params P, const PrefixArgs A)
 {
     extern __shared__ __align__(16) double lds[];
     const int H = P.horizon, n = 6 * H, m = 12 * (H + 1), L = H + 1;
     const int tid = threadIdx.x, bs = blockDim.x;
-    const Layout Y = make_layout(H, FD, SAME_DT);
+    constexpr bool FD = MODE != kEval;
+    const Layout Y = make_layout(H, MODE, SAME_DT);
     double *dec = lds;  // [H], shared by the scenarios of the workgroup
     double *scen = lds + ((H + 1) & ~1);
     const int s0 = blockIdx.x * A.S;
@@ -410,8 +420,16 @@ __global__ __launch_bounds__(128) void prefix_kernel(const mpc_params P, const P
             }
             // column `var` of dc/dx, rows of state k+1 (the other rows of the column are +-0)
             const double c1 = fmin(qnp - qlo, qhi - qnp), c0 = fmin(qnb - qlo, qhi - qnb);
-            S2[Y.jpos + 6 * (tri_j + k + 1) + a] = quot(c1 - c0, dx, rdx);
-            if (k == j) S2[Y.jvel + var] = quot((lim - fabs(xv)) - (lim - fabs(x0v)), dx, rdx);
+            const double jp = quot(c1 - c0, dx, rdx);
+            const double jv = quot((lim - fabs(xv)) - (lim - fabs(x0v)), dx, rdx);
+            if (MODE == kFused) {
+                S2[Y.jpos + 6 * (tri_j + k + 1) + a] = jp;
+                if (k == j) S2[Y.jvel + var] = jv;
+            } else if (A.jac != nullptr) {
+                double *cz = A.compact + (size_t)(s0 + ls2) * A.cstride;
+                cz[6 * H + 6 * (tri_j + k + 1) + a] = jp;
+                if (k == j) cz[var] = jv;
+            }
             k = k + 1;
         } else {
             if (A.grad != nullptr) A.grad[(size_t)(s0 + ls2) * n + var] = quot(acc - f0, dx, rdx);  // NUMDIFF:619
@@ -419,7 +437,7 @@ __global__ __launch_bounds__(128) void prefix_kernel(const mpc_params P, const P
             if (pert < npert) need_init = true; else active = false;
         }
     }
-    if (A.jac == nullptr) return;
+    if (MODE != kFused || A.jac == nullptr) return;
     __syncthreads();
 
     // ================= phase 3: dense dc/dx, column-major m x n per scenario ====================
@@ -478,6 +496,37 @@ __global__ __launch_bounds__(128) void prefix_kernel(const mpc_params P, const P
     }
 }
 
+// kCompact's second half: one wave per (scenario, step jj) writes the six dense columns of that
+// step (12(H+1) rows each) from the quotients kCompact left in the workspace.  Same row ownership
+// as phase 3 of the fused kernel: per pass a lane owns rows (t, t+1) of state kk.
+__global__ __launch_bounds__(64) void expand_kernel(int H, int count, const double *__restrict__ compact, int cstride,
+                                                    double *__restrict__ jac)
+{
+    typedef double v2d __attribute__((ext_vector_type(2)));
+    const int n = 6 * H, m = 12 * (H + 1);
+    const unsigned bid = mpck::xcd_remap(blockIdx.x, gridDim.x);
+    const int s = bid / H, jj = bid - s * H;
+    if (s >= count) return;
+    const int lane = threadIdx.x;
+    const double *cz = compact + (size_t)s * cstride;
+    double *out = jac + ((size_t)s * n + 6 * jj) * m;
+    const int tj = jj * H - (jj * (jj - 1)) / 2 - jj - 1;
+    for (int r0 = 2 * lane; r0 < m; r0 += 128) {
+        const int kk = r0 / 12, g = (r0 - 12 * kk) >> 1;
+        const bool is_pos = g < 3;
+        const int gp = is_pos ? g : g - 3;
+        const bool hot = is_pos ? (kk > jj) : (kk == jj + 1);
+        v2d val = {0.0, 0.0};
+        if (hot) val = *reinterpret_cast<const v2d *>(is_pos ? cz + 6 * H + 6 * (tj + kk) + 2 * gp : cz + 6 * jj + 2 * gp);
+#pragma unroll
+        for (int aa = 0; aa < 6; ++aa) {
+            const bool mine = gp == (aa >> 1);
+            const v2d v = (aa & 1) ? v2d{0.0, mine ? val.y : 0.0} : v2d{mine ? val.x : 0.0, 0.0};
+            *reinterpret_cast<v2d *>(out + (size_t)aa * m + r0) = v;
+        }
+    }
+}
+
 bool ur_pattern(const mpc_params &P)
 {
     const double ca[6] = {0, 1, 1, 0, 0, 1}, sa[6] = {1, 0, 0, 1, -1, 0};
@@ -492,49 +541,110 @@ bool ur_pattern(const mpc_params &P)
 
 struct Geometry { int S, items, threads; size_t lds; };
 
-Geometry geometry(const mpc_params &P, bool fd)
+Geometry geometry(const mpc_params &P, int mode)
 {
     const int H = P.horizon, L = H + 1;
     const bool same_dt = P.dt_cost == P.dt_con;
     Geometry g;
     g.items = 6 * ((H + 1) / 2);
-    const int lanes = fd ? (g.items > L ? g.items : L) : L;  // lanes one scenario needs
+    const int lanes = (mode != kEval) ? (g.items > L ? g.items : L) : L;  // lanes one scenario needs
     g.S = lanes <= 64 ? 64 / lanes : 1;
     g.threads = ((g.S * lanes + 63) / 64) * 64;
-    g.lds = sizeof(double) * ((size_t)((H + 1) & ~1) + (size_t)g.S * make_layout(H, fd, same_dt).total);
+    g.lds = sizeof(double) * ((size_t)((H + 1) & ~1) + (size_t)g.S * make_layout(H, mode, same_dt).total);
     return g;
+}
+
+bool fused_ok(const mpc_params &P)
+{
+    const Geometry g = geometry(P, kFused);
+    return g.threads <= 128 && g.lds <= (size_t)kMaxLdsBytes && 12 * (P.horizon + 1) <= 512;
+}
+
+bool compact_ok(const mpc_params &P)
+{
+    const Geometry g = geometry(P, kCompact);
+    return g.threads <= 512 && g.lds <= (size_t)kMaxLdsLarge;
+}
+
+template <int MODE, int MAXT>
+hipError_t launch_mode(const mpc_params &P, const PrefixArgs &A, const Geometry &g, unsigned grid, hipStream_t stream)
+{
+    const bool same_dt = P.dt_cost == P.dt_con;
+    if (g.lds > 48 * 1024) {  // above the default dynamic-LDS limit
+        hipError_t e = same_dt ? hipFuncSetAttribute(reinterpret_cast<const void *>(prefix_kernel<MODE, true, MAXT>),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds)
+                               : hipFuncSetAttribute(reinterpret_cast<const void *>(prefix_kernel<MODE, false, MAXT>),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds);
+        if (e != hipSuccess) return e;
+    }
+    if (same_dt) hipLaunchKernelGGL((prefix_kernel<MODE, true, MAXT>), dim3(grid), dim3(g.threads), g.lds, stream, P, A);
+    else hipLaunchKernelGGL((prefix_kernel<MODE, false, MAXT>), dim3(grid), dim3(g.threads), g.lds, stream, P, A);
+    return hipGetLastError();
 }
 
 }  // namespace
 
 namespace mpck {
 
-bool prefix_supported(const mpc_params &P)
+bool prefix_supported(const mpc_params &P) { return ur_pattern(P) && (fused_ok(P) || compact_ok(P)); }
+
+size_t prefix_workspace_doubles_per_scenario(const mpc_params &P)
 {
-    if (!ur_pattern(P)) return false;
-    const Geometry g = geometry(P, true);
-    return g.threads <= 128 && g.lds <= (size_t)kMaxLdsBytes && 12 * (P.horizon + 1) <= 512;
+    if (!ur_pattern(P) || fused_ok(P) || !compact_ok(P)) return 0;
+    const size_t H = (size_t)P.horizon;
+    return 6 * H + 3 * H * (H + 1);
 }
 
 hipError_t launch_prefix(const mpc_params &P, const double *decay, const mpc_scenarios &sc, const double *x,
-                         double *cost, double *grad, double *con, double *jac, hipStream_t stream)
+                         double *cost, double *grad, double *con, double *jac, double *workspace,
+                         size_t workspace_doubles, hipStream_t stream)
 {
-    const bool fd = grad != nullptr || jac != nullptr;
-    const Geometry g = geometry(P, fd);
     if (!prefix_supported(P)) return hipErrorNotSupported;
+    const bool fd = grad != nullptr || jac != nullptr;
+    const bool fused = fused_ok(P);
+    const int mode = !fd ? kEval : (fused ? kFused : kCompact);
+    const Geometry g = geometry(P, mode);
+    const int H = P.horizon, n = 6 * H, m = 12 * (H + 1);
     PrefixArgs A;
     A.decay = decay; A.sc = sc; A.x = x; A.cost = cost; A.grad = grad; A.con = con; A.jac = jac;
+    A.compact = nullptr; A.cstride = 0;
     A.S = g.S; A.items = g.items;
-    const unsigned grid = (unsigned)((sc.count + g.S - 1) / g.S);
-    const bool same_dt = P.dt_cost == P.dt_con;
-    if (fd) {
-        if (same_dt) hipLaunchKernelGGL((prefix_kernel<true, true>), dim3(grid), dim3(g.threads), g.lds, stream, P, A);
-        else hipLaunchKernelGGL((prefix_kernel<true, false>), dim3(grid), dim3(g.threads), g.lds, stream, P, A);
-    } else {
-        if (same_dt) hipLaunchKernelGGL((prefix_kernel<false, true>), dim3(grid), dim3(g.threads), g.lds, stream, P, A);
-        else hipLaunchKernelGGL((prefix_kernel<false, false>), dim3(grid), dim3(g.threads), g.lds, stream, P, A);
+    if (mode != kCompact) {
+        const unsigned grid = (unsigned)((sc.count + g.S - 1) / g.S);
+        if (mode == kEval) return fused ? launch_mode<kEval, 128>(P, A, g, grid, stream) : launch_mode<kEval, 512>(P, A, g, grid, stream);
+        return launch_mode<kFused, 128>(P, A, g, grid, stream);
     }
-    return hipGetLastError();
+    // long horizon: scenarios go through the workspace in chunks (kernel A, then the expansion)
+    const size_t per = prefix_workspace_doubles_per_scenario(P);
+    int chunk = sc.count;
+    if (jac != nullptr) {
+        if (workspace == nullptr || workspace_doubles < per) return hipErrorInvalidValue;
+        const size_t fit = workspace_doubles / per;
+        if (fit < (size_t)chunk) chunk = (int)fit;
+    }
+    for (int first = 0; first < sc.count; first += chunk) {
+        const int cnt = (sc.count - first < chunk) ? sc.count - first : chunk;
+        PrefixArgs B = A;
+        B.sc.count = cnt;
+        B.sc.state0 += (size_t)first * 18; B.sc.target += (size_t)first * 6;
+        B.sc.base_traj += (size_t)first * 12 * H; B.sc.Jc += (size_t)first * 36;
+        if (B.sc.u_prev) B.sc.u_prev += (size_t)first * 6;
+        if (B.sc.has_prev) B.sc.has_prev += first;
+        B.x += (size_t)first * n; B.cost += first;
+        if (B.grad) B.grad += (size_t)first * n;
+        if (B.con) B.con += (size_t)first * m;
+        if (B.jac) B.jac += (size_t)first * n * m;
+        B.compact = workspace; B.cstride = (int)per;
+        hipError_t e = launch_mode<kCompact, 512>(P, B, g, (unsigned)cnt, stream);
+        if (e != hipSuccess) return e;
+        if (jac != nullptr) {
+            hipLaunchKernelGGL(expand_kernel, dim3((unsigned)cnt * (unsigned)H), dim3(64), 0, stream, H, cnt, workspace,
+                               (int)per, B.jac);
+            e = hipGetLastError();
+            if (e != hipSuccess) return e;
+        }
+    }
+    return hipSuccess;
 }
 
 }  // namespace mpck

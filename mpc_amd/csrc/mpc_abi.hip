@@ -19,12 +19,16 @@ struct mpc_ctx {
     mpc_params params{};
     double *d_decay = nullptr;  // [H]
     double *d_fvals = nullptr;  // [max_scenarios][n+1], MPC_ALGO_ROLLOUT only
+    double *d_work = nullptr;   // long-horizon MPC_ALGO_PREFIX: FD quotients between its two kernels
+    size_t work_doubles = 0;
     char err[512] = {0};
 };
 
 namespace {
 
 thread_local char g_err[512] = {0};
+
+constexpr size_t kWorkCapBytes = size_t(2) << 30;
 
 int fail(mpc_ctx *ctx, int code, const char *fmt, ...)
 {
@@ -118,6 +122,7 @@ void mpc_ctx_destroy(mpc_ctx *ctx)
     (void)hipSetDevice(ctx->device);
     if (ctx->d_decay) (void)hipFree(ctx->d_decay);
     if (ctx->d_fvals) (void)hipFree(ctx->d_fvals);
+    if (ctx->d_work) (void)hipFree(ctx->d_work);
     delete ctx;
 }
 
@@ -145,6 +150,20 @@ int mpc_set_params(mpc_ctx *ctx, const mpc_params *p, const double *decay_host, 
         return fail(ctx, MPC_ERR_UNSUPPORTED, "MPC_ALGO_PREFIX does not support these parameters");
     MPC_HIP(ctx, hipSetDevice(ctx->device));
     MPC_HIP(ctx, hipMemcpy(ctx->d_decay, decay_host, sizeof(double) * (size_t)n_decay, hipMemcpyHostToDevice));
+    // long horizons: workspace for the FD quotients, at most kWorkCapBytes (batches go through it in chunks)
+    const size_t per = (p->algo != MPC_ALGO_ROLLOUT) ? mpck::prefix_workspace_doubles_per_scenario(*p) : 0;
+    size_t want = per * (size_t)ctx->max_scenarios;
+    const size_t cap = kWorkCapBytes / sizeof(double);
+    if (want > cap) want = (cap / per) * per;
+    if (want < per) want = per;
+    if (per == 0) want = 0;
+    if (want != ctx->work_doubles) {
+        if (ctx->d_work) (void)hipFree(ctx->d_work);
+        ctx->d_work = nullptr;
+        ctx->work_doubles = 0;
+        if (want) MPC_HIP(ctx, hipMalloc(&ctx->d_work, want * sizeof(double)));
+        ctx->work_doubles = want;
+    }
     ctx->params = *p;
     ctx->have_params = true;
     return MPC_OK;
@@ -159,6 +178,11 @@ int mpc_eval(mpc_ctx *ctx, const mpc_scenarios *sc, const double *x, double *cos
     if (sc->count == 0) return MPC_OK;
     if (!cost) return fail(ctx, MPC_ERR_INVALID_ARG, "cost is NULL");
     MPC_HIP(ctx, hipSetDevice(ctx->device));
+    if (resolve_algo(ctx) == MPC_ALGO_PREFIX) {  // phase 1 of the prefix kernel: bit-identical f to mpc_eval_fd's
+        MPC_HIP(ctx, mpck::launch_prefix(ctx->params, ctx->d_decay, *sc, x, cost, nullptr, con, nullptr, nullptr, 0,
+                                         static_cast<hipStream_t>(stream)));
+        return MPC_OK;
+    }
     MPC_HIP(ctx, mpck::launch_rollout(ctx->params, ctx->d_decay, *sc, x, cost, 1, con, nullptr, 0,
                                       static_cast<hipStream_t>(stream)));
     return MPC_OK;
@@ -176,7 +200,8 @@ int mpc_eval_fd(mpc_ctx *ctx, const mpc_scenarios *sc, const double *x, double *
     hipStream_t st = static_cast<hipStream_t>(stream);
     MPC_HIP(ctx, hipSetDevice(ctx->device));
     if (resolve_algo(ctx) == MPC_ALGO_PREFIX) {
-        MPC_HIP(ctx, mpck::launch_prefix(ctx->params, ctx->d_decay, *sc, x, cost, grad, con, con_jac, st));
+        MPC_HIP(ctx, mpck::launch_prefix(ctx->params, ctx->d_decay, *sc, x, cost, grad, con, con_jac, ctx->d_work,
+                                         ctx->work_doubles, st));
         return MPC_OK;
     }
     const int n = 6 * ctx->horizon;

@@ -19,9 +19,13 @@ hipError_t launch_fd_finalize(const mpc_params &P, int N, const double *x, const
                               double *grad, hipStream_t stream);
 
 // MPC_ALGO_PREFIX: one workgroup per scenario, shared-prefix perturbed rollouts.
+// `workspace` (device, `workspace_doubles` long) is only used for long horizons; its size per
+// scenario is prefix_workspace_doubles_per_scenario() (0 when the fused kernel serves P).
 hipError_t launch_prefix(const mpc_params &P, const double *decay, const mpc_scenarios &sc, const double *x,
-                         double *cost, double *grad, double *con, double *jac, hipStream_t stream);
+                         double *cost, double *grad, double *con, double *jac, double *workspace,
+                         size_t workspace_doubles, hipStream_t stream);
 bool prefix_supported(const mpc_params &P);
+size_t prefix_workspace_doubles_per_scenario(const mpc_params &P);
 
 hipError_t launch_jacobian(const mpc_params &P, int N, const double *q, double *J, hipStream_t stream);
 hipError_t launch_fk(const mpc_params &P, int N, const double *q, double *pose, hipStream_t stream);
