@@ -163,3 +163,69 @@ def test_empty_batch_and_bad_arguments():
     big, xb = to_device(ctx, host_scenarios(mp, 9)[1])
     with pytest.raises(ValueError):
         ctx.eval_fd(big, xb)                           # more scenarios than the context was sized for
+
+
+def test_full_size_properties_65536_angular():
+    """BASELINE configs[2] shape (65,536 angular-motion scenarios, H=20) through size-independent
+    properties: scenarios are independent, so (i) a permuted batch gives the permuted outputs bit for
+    bit, (ii) two half batches equal the full batch, (iii) a repeat launch is bit-identical; a strided
+    sample is checked against the CPU oracle."""
+    N = 65536
+    mp = params_for(20)
+    ctx = _ctx(mp, N)
+    co, hs = host_scenarios(mp, N, motion="angular", cfg_id=3, with_prev=True)
+    sc, x = to_device(ctx, hs)
+    r = ctx.eval_fd(sc, x, want_jac=False)
+    torch.cuda.synchronize()
+    cost, grad, con = r.cost.clone(), r.grad.clone(), r.con.clone()
+    r2 = ctx.eval_fd(sc, x, want_jac=False)
+    assert torch.equal(r2.cost, cost) and torch.equal(r2.grad, grad) and torch.equal(r2.con, con)
+    perm = torch.randperm(N, device=ctx.device, generator=torch.Generator(device=ctx.device).manual_seed(1))
+    from mpc_amd.solver import _gather
+    scp = _gather(sc, perm.cpu().numpy(), ctx.device)
+    rp = ctx.eval_fd(scp, x[perm].contiguous(), want_jac=False)
+    assert torch.equal(rp.cost, cost[perm]) and torch.equal(rp.grad, grad[perm]) and torch.equal(rp.con, con[perm])
+    h = N // 2
+    ra = ctx.eval_fd(sc.slice(0, h), x[:h], want_jac=False)
+    rb = ctx.eval_fd(sc.slice(h, N), x[h:], want_jac=False)
+    assert torch.equal(torch.cat([ra.cost, rb.cost]), cost) and torch.equal(torch.cat([ra.grad, rb.grad]), grad)
+    idx = np.arange(0, N, 1024)
+    sub = {k: (None if v is None else v[idx]) for k, v in hs.as_oracle_dict().items()}
+    c_o, g_o, con_o, _ = co.eval_fd(sub, want_jac=False)
+    assert_cost_close(cost.cpu().numpy()[idx], c_o)
+    assert_grad_close(grad.cpu().numpy()[idx], g_o)
+    np.testing.assert_allclose(con.cpu().numpy()[idx], con_o, rtol=1e-13, atol=1e-13)
+    # dense Jacobian on a 4,096-scenario slice: exact zero pattern, and the non-zeros reproduce the
+    # constraint's own finite difference (-sign(u) on the velocity rows, +-dt-sized on the position rows)
+    rj = ctx.eval_fd(sc.slice(0, 4096), x[:4096])
+    J = rj.con_jac.view(4096, 20, 6, 21, 12)            # [s][j][a][k][row in state]
+    assert float(J[:, :, :, 0, :].abs().max()) == 0.0   # state 0 does not depend on x
+    kidx = torch.arange(21, device=ctx.device)
+    jidx = torch.arange(20, device=ctx.device)
+    upper = (kidx[None, :] <= jidx[:, None])            # states k <= j are untouched by u_j
+    assert float(J.permute(0, 2, 4, 1, 3)[..., upper].abs().max()) == 0.0
+    vel = torch.stack([J[:, j, :, j + 1, 6:] for j in range(20)], dim=1)   # [s][j][a][6]
+    diag = torch.diagonal(vel, dim1=2, dim2=3)
+    u = x[:4096].view(4096, 20, 6)
+    away = u.abs() > 2e-3                               # the step does not straddle |u| = 0 there
+    assert torch.allclose(diag[away], -torch.sign(u)[away], atol=1e-9)
+
+
+def test_h100_batch_in_chunks_equals_one_pass():
+    """Long-horizon path: the workspace-chunked two-kernel route is independent of the batch split."""
+    mp = params_for(100)
+    N = 48
+    ctx = _ctx(mp, N)
+    co, hs = host_scenarios(mp, N, motion="linear", cfg_id=4)
+    sc, x = to_device(ctx, hs)
+    full = ctx.eval_fd(sc, x)
+    parts = [ctx.eval_fd(sc.slice(a, a + 16), x[a:a + 16]) for a in (0, 16, 32)]
+    torch.cuda.synchronize()
+    assert torch.equal(torch.cat([p.con_jac for p in parts]), full.con_jac)
+    assert torch.equal(torch.cat([p.grad for p in parts]), full.grad)
+    idx = np.array([0, 47])
+    sub = {k: (None if v is None else v[idx]) for k, v in hs.as_oracle_dict().items()}
+    c_o, g_o, con_o, jac_o = co.eval_fd(sub)
+    assert_cost_close(full.cost.cpu().numpy()[idx], c_o)
+    assert_grad_close(full.grad.cpu().numpy()[idx], g_o)
+    np.testing.assert_allclose(full.con_jac.cpu().numpy()[idx], jac_o, rtol=1e-9, atol=1e-10)
