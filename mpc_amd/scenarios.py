@@ -77,6 +77,38 @@ def dls_guess(Jc: np.ndarray, base: np.ndarray, ee_pos: np.ndarray) -> np.ndarra
     return (np.transpose(J, (0, 2, 1)) @ y)[:, :, 0]
 
 
+def platform_state(motion: str, amplitude: np.ndarray, phase: np.ndarray, t: float = 0.0) -> np.ndarray:
+    """Platform state [P, Theta, V, Omega] at time t of the motion the reference's simulator drives
+    (tests/simulate_platform_motion.py:42-59): velocity command A w cos(w t + phi) on the prismatic x
+    axis ('linear', A in m) or about z ('angular', A in rad)."""
+    amplitude = np.atleast_1d(np.asarray(amplitude, float))
+    phase = np.atleast_1d(np.asarray(phase, float))
+    w = 2.0 * np.pi * PLATFORM_FREQ_HZ
+    base = np.zeros((amplitude.shape[0], 12))
+    pos, vel = amplitude * np.sin(w * t + phase), amplitude * w * np.cos(w * t + phase)
+    if motion == "linear":
+        base[:, 0], base[:, 6] = pos, vel
+    elif motion == "angular":
+        base[:, 5], base[:, 11] = pos, vel
+    else:
+        raise ValueError("motion must be 'linear' or 'angular'")
+    return base
+
+
+def world_ee_pose(pose_local: np.ndarray, base: np.ndarray) -> np.ndarray:
+    """Tip pose in the world: platform pose o arm mount (mpc_robot.xacro:17-22) o FK in base_link."""
+    yaw = base[:, 5]
+    local = ARM_OFFSET + pose_local[:, 0:3]
+    c, s = np.cos(yaw), np.sin(yaw)
+    out = np.empty((pose_local.shape[0], 6))
+    out[:, 0] = base[:, 0] + c * local[:, 0] - s * local[:, 1]
+    out[:, 1] = base[:, 1] + s * local[:, 0] + c * local[:, 1]
+    out[:, 2] = base[:, 2] + local[:, 2]
+    out[:, 3:6] = pose_local[:, 3:6]
+    out[:, 5] += yaw
+    return out
+
+
 def make_scenarios(params: MpcParams, kin, count: int, motion: str = "linear", cfg_id: int = 2,
                    with_prev: bool = False, goal_jitter: float = 0.05, first: int = 0) -> HostScenarios:
     """Scenarios ``first .. first+count-1`` of configuration ``cfg_id``.  Row i depends only on
@@ -91,26 +123,11 @@ def make_scenarios(params: MpcParams, kin, count: int, motion: str = "linear", c
         rng.bit_generator.advance(first * K)
     U = rng.random((count, K))
     q0 = (Q_LINEAR_READY if motion == "linear" else Q_ANGULAR_READY) + (U[:, 0:6] * 0.2 - 0.1)
-    w = 2.0 * np.pi * PLATFORM_FREQ_HZ
     phi = U[:, 7] * 2.0 * np.pi
-    base = np.zeros((count, 12))
-    if motion == "linear":
-        A = 0.05 + U[:, 6] * 0.25
-        base[:, 0] = A * np.sin(phi)
-        base[:, 6] = A * w * np.cos(phi)
-    else:
-        A = np.radians(5.0 + U[:, 6] * 25.0)
-        base[:, 5] = A * np.sin(phi)
-        base[:, 11] = A * w * np.cos(phi)
-    pose = np.asarray(kin.fk(q0))                          # tip in base_link
-    yaw = base[:, 5]
-    local = ARM_OFFSET + pose[:, 0:3]
-    c, s = np.cos(yaw), np.sin(yaw)
-    p0 = np.stack([base[:, 0] + c * local[:, 0] - s * local[:, 1],
-                   base[:, 1] + s * local[:, 0] + c * local[:, 1],
-                   base[:, 2] + local[:, 2]], axis=1)
-    o0 = pose[:, 3:6].copy()
-    o0[:, 2] += yaw
+    A = (0.05 + U[:, 6] * 0.25) if motion == "linear" else np.radians(5.0 + U[:, 6] * 25.0)
+    base = platform_state(motion, A, phi)
+    ee0 = world_ee_pose(np.asarray(kin.fk(q0)), base)      # FK gives the tip in base_link
+    p0, o0 = ee0[:, 0:3], ee0[:, 3:6]
     state0 = np.concatenate([q0, np.zeros((count, 6)), p0, o0], axis=1)   # dq0 = 0 (mpc_action_server.py:83)
     target = np.concatenate([p0, o0], axis=1) + (U[:, 8:14] * 2.0 - 1.0) * goal_jitter
     base_traj = np.asarray(kin.predict_base_dynamic(base))
@@ -122,8 +139,10 @@ def make_scenarios(params: MpcParams, kin, count: int, motion: str = "linear", c
     active = ~((np.linalg.norm(base[:, 6:9], axis=1) < 0.01) & (np.linalg.norm(base[:, 9:12], axis=1) < 0.01))
     u_prev = x[:, :6].copy() if with_prev else None
     has_prev = np.ones(count, dtype=np.uint8) if with_prev else None
-    return HostScenarios(motion, q0, base, state0, target, base_traj, Jc, np.ascontiguousarray(x), u_init,
-                         u_prev, has_prev, active)
+    hs = HostScenarios(motion, q0, base, state0, target, base_traj, Jc, np.ascontiguousarray(x), u_init,
+                       u_prev, has_prev, active)
+    hs.amplitude, hs.phase = A, phi
+    return hs
 
 
 class DeviceKinematics:

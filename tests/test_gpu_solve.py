@@ -114,3 +114,37 @@ def test_batched_solver_equals_single_scenario_driver():
                        options={"ftol": 1e-3, "maxiter": 50})
         np.testing.assert_allclose(res.x[i], ref.x, rtol=0, atol=1e-12)
         assert res.nit[i] == ref.nit and res.status[i] == ref.status
+
+
+@pytest.mark.parametrize("motion,H", [("linear", 3), ("angular", 3), ("linear", 1)])
+def test_closed_loop_trajectory_matches_reference_path(motion, H):
+    """Six ticks of the headless loop: the joint trajectory of the batched GPU controllers stays within
+    1e-6 rad of the numpy restatement of the reference driven through the same loop (which is
+    bit-identical to the reference's compute_control, tests/test_oracle.py)."""
+    from helpers import host_scenarios
+    from mpc_amd.batch import MpcContext
+    from mpc_amd.closed_loop import run_closed_loop
+    from mpc_amd.scenarios import platform_state, world_ee_pose
+    from oracle.numpy_ref import NumpyRefMPC, ur20_fk
+    from oracle.oracle import ref_params_from
+
+    mp = MpcParams.reference_yaml_defaults(horizon=H)
+    _, hs = host_scenarios(mp, 4, motion=motion, cfg_id=7)
+    ticks = 6
+    ctx = MpcContext(mp, 4, 0)
+    got = run_closed_loop(ctx, hs.q0, motion, hs.amplitude, hs.phase, ticks)
+    for i in range(4):
+        ref = NumpyRefMPC(ref_params_from(mp))
+        q = hs.q0[i].copy()
+        fk = lambda qq, b: world_ee_pose(np.concatenate(ur20_fk(qq))[None], b)[0]
+        base = platform_state(motion, hs.amplitude[i], hs.phase[i], 0.0)
+        ee = fk(q, base)
+        target = {"position": ee[:3].copy(), "orientation": ee[3:].copy()}
+        for t in range(ticks):
+            b = platform_state(motion, hs.amplitude[i], hs.phase[i], t * mp.dt)[0]
+            bs = {"position": b[0:3], "orientation": b[3:6], "linear_velocity": b[6:9], "angular_velocity": b[9:12]}
+            u = ref.compute_control({"position": q, "velocity": np.zeros(6)},
+                                    {"position": ee[:3], "orientation": ee[3:]}, target, bs)
+            q = q + u * mp.dt
+            ee = fk(q, platform_state(motion, hs.amplitude[i], hs.phase[i], (t + 1) * mp.dt))
+            np.testing.assert_allclose(got.q[t + 1, i], q, rtol=0, atol=SOL_ATOL)
