@@ -112,7 +112,8 @@ def solve_rate(ctx, mp, count):
     return {"value": int(hs.active.sum()) / dt, "unit": "solves/s", "sample": f"{count} angular-motion scenarios, H={mp.horizon}, "
             f"one tick each, {int(r.success.sum())} converged, {r.rounds} lock-step rounds, "
             f"{r.n_eval_fd} eval_fd + {r.n_eval} eval scenario-evals on the GPU, SLSQP core on 1 host core",
-            "host_bound": True, "seconds": dt, "mean_iterations": float(r.nit.mean())}
+            "host_bound": True, "seconds": dt, "mean_iterations": float(r.nit.mean()),
+            "seconds_in_slsqp_core": r.t_core, "seconds_in_device_calls_and_copies": r.t_serve}
 
 
 def main():

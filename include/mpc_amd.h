@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MPC_AMD_ABI_VERSION 1
+#define MPC_AMD_ABI_VERSION 2
 #define MPC_MAX_HORIZON 255
 
 typedef enum mpc_status {
@@ -134,6 +134,15 @@ int mpc_fk(mpc_ctx *ctx, int count, const double *q, double *pose, void *stream)
  * dyn_host[6] = {mass, I_z, k_v, k_omega, tau_linear, tau_angular} (HOST pointer) -> base_traj [N][H][12]. */
 int mpc_predict_base_dynamic(mpc_ctx *ctx, int count, const double *base, const double *dyn_host,
                              double *base_traj, void *stream);
+
+/* Active-set gather for lock-step solves: scipy's driver evaluates a problem only when its SLSQP core
+ * asks (mode 1 / -1, _slsqp_py.py:427-456), so each round of a batched solve touches a changing subset
+ * of the scenarios.  Copies rows index[i] (device int32[count], each in [0, src->count)) of every array
+ * of `src` to row i of `dst` in one launch; optional arrays are copied when both sides have them.
+ * Rows whose index is out of range are filled with NaN (never read out of bounds).  dst->count is
+ * ignored (dst must hold `count` rows). */
+int mpc_gather_scenarios(mpc_ctx *ctx, const mpc_scenarios *src, const int32_t *index, int count,
+                         const mpc_scenarios *dst, void *stream);
 
 /* Text of the last error recorded on ctx (or on the calling thread when ctx is NULL). */
 const char *mpc_last_error(const mpc_ctx *ctx);

@@ -53,6 +53,14 @@ class ScenarioBatch:
                    up(None if u_prev is None else np.asarray(u_prev).reshape(N, 6)),
                    up(None if has_prev is None else np.asarray(has_prev).reshape(N), torch.uint8))
 
+    @classmethod
+    def empty(cls, device, count: int, horizon: int, with_prev: bool) -> "ScenarioBatch":
+        dev = torch.device("cuda", _dev_index(device))
+        z = lambda *shape: torch.empty(shape, dtype=torch.float64, device=dev)
+        return cls(z(count, 18), z(count, 6), z(count, horizon, 12), z(count, 36),
+                   z(count, 6) if with_prev else None,
+                   torch.zeros(count, dtype=torch.uint8, device=dev) if with_prev else None)
+
     def slice(self, lo: int, hi: int) -> "ScenarioBatch":
         f = lambda t: None if t is None else t[lo:hi]
         return ScenarioBatch(f(self.state0), f(self.target), f(self.base_traj), f(self.Jc), f(self.u_prev),
@@ -120,9 +128,9 @@ class MpcContext:
             raise ValueError(f"{name} has shape {tuple(t.shape)}, expected {tuple(shape)}")
         return t.data_ptr()
 
-    def _scen_c(self, sc: ScenarioBatch) -> _ffi.MpcScenariosC:
+    def _scen_c(self, sc: ScenarioBatch, limit: bool = True) -> _ffi.MpcScenariosC:
         N = sc.count
-        if N > self.max_scenarios:
+        if limit and N > self.max_scenarios:
             raise ValueError(f"{N} scenarios > max_scenarios {self.max_scenarios}")
         c = _ffi.MpcScenariosC()
         c.count = N
@@ -171,6 +179,19 @@ class MpcContext:
         _ffi.check(self._ctx, self._lib.mpc_eval_fd(self._ctx, C.byref(scc), xp, cost.data_ptr(), gp, cp, jp,
                                                     self._stream()))
         return EvalResult(cost, grad, con, jac)
+
+    def gather(self, src: ScenarioBatch, index: torch.Tensor, out: ScenarioBatch) -> ScenarioBatch:
+        """Rows ``index`` (int32 device tensor [k], values in [0, src.count)) of ``src`` -> the first k
+        rows of ``out`` in one launch; returns that k-row view of ``out``."""
+        k = int(index.shape[0])
+        if k > out.count:
+            raise ValueError(f"{k} rows gathered into a batch of {out.count}")
+        ip = self._chk(index, (k,), "index", dtype=torch.int32)
+        dst = out.slice(0, k)
+        if k:
+            _ffi.check(self._ctx, self._lib.mpc_gather_scenarios(
+                self._ctx, C.byref(self._scen_c(src, limit=False)), ip, k, C.byref(self._scen_c(dst)), self._stream()))
+        return dst
 
     # ---- the steps either side of it -------------------------------------------------------
     def jacobian(self, q: torch.Tensor) -> torch.Tensor:

@@ -109,4 +109,38 @@ hipError_t launch_predict_base_dynamic(int N, int H, double dt, const double *ba
     return hipGetLastError();
 }
 
+// One workgroup per gathered row; the row's arrays are copied as one flat run of doubles.
+__global__ void __launch_bounds__(128)
+gather_scenarios_kernel(int H, mpc_scenarios src, const int32_t *__restrict__ index, mpc_scenarios dst)
+{
+    const int i = (int)blockIdx.x;
+    const int r = index[i];
+    const bool ok = r >= 0 && r < src.count;
+    const double nan = __longlong_as_double(0x7ff8000000000000LL);
+    const int nb = 12 * H;
+    const bool prev = src.u_prev != nullptr && dst.u_prev != nullptr;
+    const int total = 18 + 6 + 36 + nb + (prev ? 6 : 0);
+    for (int f = (int)threadIdx.x; f < total; f += (int)blockDim.x) {
+        if (f < 18)
+            const_cast<double *>(dst.state0)[(size_t)i * 18 + f] = ok ? src.state0[(size_t)r * 18 + f] : nan;
+        else if (f < 24)
+            const_cast<double *>(dst.target)[(size_t)i * 6 + (f - 18)] = ok ? src.target[(size_t)r * 6 + (f - 18)] : nan;
+        else if (f < 60)
+            const_cast<double *>(dst.Jc)[(size_t)i * 36 + (f - 24)] = ok ? src.Jc[(size_t)r * 36 + (f - 24)] : nan;
+        else if (f < 60 + nb)
+            const_cast<double *>(dst.base_traj)[(size_t)i * nb + (f - 60)] = ok ? src.base_traj[(size_t)r * nb + (f - 60)] : nan;
+        else
+            const_cast<double *>(dst.u_prev)[(size_t)i * 6 + (f - 60 - nb)] = ok ? src.u_prev[(size_t)r * 6 + (f - 60 - nb)] : nan;
+    }
+    if (threadIdx.x == 0 && src.has_prev != nullptr && dst.has_prev != nullptr)
+        const_cast<uint8_t *>(dst.has_prev)[i] = ok ? src.has_prev[r] : (uint8_t)0;
+}
+
+hipError_t launch_gather_scenarios(int H, const mpc_scenarios &src, const int32_t *index, int count,
+                                   const mpc_scenarios &dst, hipStream_t stream)
+{
+    hipLaunchKernelGGL(gather_scenarios_kernel, dim3((unsigned)count), dim3(128), 0, stream, H, src, index, dst);
+    return hipGetLastError();
+}
+
 }  // namespace mpck

@@ -251,4 +251,25 @@ int mpc_predict_base_dynamic(mpc_ctx *ctx, int count, const double *base, const 
     return MPC_OK;
 }
 
+int mpc_gather_scenarios(mpc_ctx *ctx, const mpc_scenarios *src, const int32_t *index, int count,
+                         const mpc_scenarios *dst, void *stream)
+{
+    int rc = check_ready(ctx);
+    if (rc) return rc;
+    if (!src || !dst || count < 0 || src->count < 0) return fail(ctx, MPC_ERR_INVALID_ARG, "bad src/dst/count");
+    if (count == 0) return MPC_OK;
+    if (!index) return fail(ctx, MPC_ERR_INVALID_ARG, "index is NULL");
+    if (!src->state0 || !src->target || !src->base_traj || !src->Jc || !dst->state0 || !dst->target ||
+        !dst->base_traj || !dst->Jc)
+        return fail(ctx, MPC_ERR_INVALID_ARG, "state0/target/base_traj/Jc must be non-NULL on both sides");
+    if ((src->has_prev && !src->u_prev) || (dst->has_prev && !dst->u_prev))
+        return fail(ctx, MPC_ERR_INVALID_ARG, "has_prev given without u_prev");
+    if ((src->u_prev != nullptr) != (dst->u_prev != nullptr) || (src->has_prev != nullptr) != (dst->has_prev != nullptr))
+        return fail(ctx, MPC_ERR_INVALID_ARG, "u_prev/has_prev must be present on both sides or on neither");
+    MPC_HIP(ctx, hipSetDevice(ctx->device));
+    MPC_HIP(ctx, mpck::launch_gather_scenarios(ctx->horizon, *src, index, count, *dst,
+                                               static_cast<hipStream_t>(stream)));
+    return MPC_OK;
+}
+
 }  // extern "C"

@@ -32,6 +32,10 @@ hipError_t launch_fk(const mpc_params &P, int N, const double *q, double *pose, 
 hipError_t launch_predict_base_dynamic(int N, int H, double dt, const double *base, const double (&dyn)[6],
                                        double *out, hipStream_t stream);
 
+// dst row i = src row index[i] for every scenario array (NaN rows for an index outside [0, src.count))
+hipError_t launch_gather_scenarios(int H, const mpc_scenarios &src, const int32_t *index, int count,
+                                   const mpc_scenarios &dst, hipStream_t stream);
+
 // Blocks b and b+8 share an XCD (round-robin dispatch): give every XCD one contiguous range of
 // logical ids so that the workgroups of one scenario hit the same L2.  Bijective for any grid.
 __device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nwg)

@@ -16,6 +16,8 @@ exactly the memory layout the core wants (column-major m x (n+1) with a zero las
 """
 from __future__ import annotations
 
+import os
+import time
 from dataclasses import dataclass
 from typing import List, Optional
 
@@ -24,47 +26,7 @@ import torch
 
 from .batch import EvalResult, MpcContext, ScenarioBatch
 
-try:  # private f2py entry point of scipy <= 1.15 (signature checked in tests/test_abi_load.py)
-    from scipy.optimize._slsqp import slsqp as _slsqp_core
-except Exception as exc:  # pragma: no cover
-    _slsqp_core = None
-    _slsqp_import_error = exc
-
-EXIT_MESSAGES = {
-    -1: "Gradient evaluation required (g & a)", 0: "Optimization terminated successfully",
-    1: "Function evaluation required (f & c)", 2: "More equality constraints than independent variables",
-    3: "More than 3*n iterations in LSQ subproblem", 4: "Inequality constraints incompatible",
-    5: "Singular matrix E in LSQ subproblem", 6: "Singular matrix C in LSQ subproblem",
-    7: "Rank-deficient equality constraint subproblem HFTI", 8: "Positive directional derivative for linesearch",
-    9: "Iteration limit reached",
-}
-
-
-class _Problem:
-    """Host-side state of one SLSQP instance (the arrays `_minimize_slsqp` allocates, _slsqp_py.py:343-409)."""
-
-    __slots__ = ("x", "fx", "c", "g", "a", "w", "jw", "mode", "majiter", "acc", "scal", "ints", "done")
-
-    def __init__(self, x0, n, m, acc, maxiter, a_view):
-        n1 = n + 1
-        meq = 0
-        mineq = m - meq + n1 + n1
-        len_w = ((3 * n1 + m) * (n1 + 1) + (n1 - meq + 1) * (mineq + 2) + 2 * mineq + (n1 + mineq) * (n1 - meq)
-                 + 2 * meq + n1 + ((n + 1) * n) // 2 + 2 * m + 3 * n + 3 * n1 + 1)
-        self.x = x0
-        self.fx = 0.0
-        self.c = np.zeros(m)
-        self.g = np.zeros(n1)
-        self.a = a_view                      # (m, n+1) Fortran-ordered view into the batch array
-        self.w = np.zeros(len_w)
-        self.jw = np.zeros(mineq)
-        self.mode = np.array(0, int)
-        self.majiter = np.array(maxiter - 1, int)
-        self.acc = np.array(acc, float)
-        self.scal = [np.array(0, float) for _ in range(9)]   # alpha, f0, gs, h1..h4, t, t0
-        self.scal.append(np.array(0, float))                 # tol
-        self.ints = [np.array(0, int) for _ in range(8)]     # iexact, incons, ireset, itermx, line, n1, n2, n3
-        self.done = False
+from .slsqp_state import EXIT_MESSAGES, Problem, require_core  # noqa: F401
 
 
 @dataclass
@@ -76,6 +38,8 @@ class BatchSolveResult:
     rounds: int            # lock-step rounds = device launches of each kind at most
     n_eval: int            # scenario-evals served by mpc_eval   (f, c)
     n_eval_fd: int         # scenario-evals served by mpc_eval_fd (f, c, grad, dc/dx)
+    t_core: float = 0.0    # seconds inside the SLSQP core (host)
+    t_serve: float = 0.0   # seconds in device launches + transfers
 
     @property
     def success(self):
@@ -84,8 +48,7 @@ class BatchSolveResult:
 
 class BatchedSLSQP:
     def __init__(self, ctx: MpcContext):
-        if _slsqp_core is None:
-            raise ImportError(f"scipy.optimize._slsqp.slsqp is not importable: {_slsqp_import_error}")
+        require_core()
         self.ctx = ctx
         p = ctx.params
         self.n, self.m = p.n, p.m
@@ -102,28 +65,53 @@ class BatchedSLSQP:
             raise ValueError("batch larger than the context")
         X = np.clip(np.array(x0, dtype=np.float64).reshape(N, n), self.lb, self.ub)   # _slsqp_py.py:268
         A = np.zeros((N, n + 1, m))          # A[i].T is the core's a(la, n+1), column-major
-        probs: List[_Problem] = [_Problem(X[i], n, m, ctx.params.ftol, ctx.params.maxiter, A[i].T)
+        probs: List[Problem] = [Problem(X[i], n, m, ctx.params.ftol, ctx.params.maxiter, A[i].T)
                                  for i in range(N)]
         xl, xu = self.lb.copy(), self.ub.copy()
+        sub_buf = ScenarioBatch.empty(ctx.device, N, ctx.params.horizon, sc.u_prev is not None)
         n_eval = n_eval_fd = rounds = 0
+        t_core = t_serve = 0.0
+
+        prof = self.profile = {"gather": 0.0, "upload": 0.0, "kernel": 0.0, "d2h": 0.0, "scatter": 0.0}
+        profiling = bool(os.environ.get("MPC_AMD_SOLVE_PROFILE"))
+
+        def tick(key, t):
+            if profiling:
+                torch.cuda.synchronize(ctx.device)
+                now = time.perf_counter()
+                prof[key] += now - t
+                return now
+            return t
 
         def serve(idx: np.ndarray, need_grad: bool):
             """One device launch for the problems in idx; x is clipped like _clip_x_for_func."""
-            sub = _gather(sc, idx, ctx.device)
+            t = time.perf_counter()
+            if len(idx) == N:
+                sub = sc
+            else:
+                sub = ctx.gather(sc, torch.from_numpy(idx.astype(np.int32)).to(ctx.device), sub_buf)
+            t = tick("gather", t)
             xd = self._to_dev(np.clip(X[idx], self.lb, self.ub))
+            t = tick("upload", t)
             if need_grad:
                 r = ctx.eval_fd(sub, xd)
+                t = tick("kernel", t)
                 g = r.grad.cpu().numpy()
                 jac = r.con_jac.cpu().numpy()
+                t = tick("d2h", t)
                 for k, i in enumerate(idx):
                     probs[i].g[:n] = g[k]
                     probs[i].g[n] = 0.0
                     A[i, :n, :] = jac[k]
+                tick("scatter", t)
                 return r
-            return ctx.eval(sub, xd)
+            r = ctx.eval(sub, xd)
+            tick("kernel", t)
+            return r
 
         # mode 0 on entry: f, g, c, a at the start point (_slsqp_py.py:419-425)
         allidx = np.arange(N)
+        t0 = time.perf_counter()
         r = serve(allidx, True)
         f0 = r.cost.cpu().numpy()
         c0 = r.con.cpu().numpy()
@@ -131,24 +119,20 @@ class BatchedSLSQP:
             probs[i].fx = float(f0[i])
             probs[i].c[:] = c0[i]
         n_eval_fd += N
+        t_serve += time.perf_counter() - t0
         active = list(range(N))
         while active:
             rounds += 1
             want_f, want_g = [], []
+            t0 = time.perf_counter()
             for i in active:
-                p = probs[i]
-                s = p.scal
-                it = p.ints
-                _slsqp_core(m, 0, p.x, xl, xu, p.fx, p.c, p.g, p.a, p.acc, p.majiter, p.mode, p.w, p.jw,
-                            s[0], s[1], s[2], s[3], s[4], s[5], s[6], s[7], s[8], s[9],
-                            it[0], it[1], it[2], it[3], it[4], it[5], it[6], it[7])
-                md = int(p.mode)
+                md = probs[i].step(xl, xu)
                 if md == 1:
                     want_f.append(i)
                 elif md == -1:
                     want_g.append(i)
-                else:
-                    p.done = True
+            t1 = time.perf_counter()
+            t_core += t1 - t0
             if want_f:
                 idx = np.array(want_f)
                 r = serve(idx, False)
@@ -161,10 +145,12 @@ class BatchedSLSQP:
             if want_g:
                 serve(np.array(want_g), True)
                 n_eval_fd += len(want_g)
+            t_serve += time.perf_counter() - t1
             active = [i for i in active if not probs[i].done]
         return BatchSolveResult(
             x=X, fun=np.array([p.fx for p in probs]), nit=np.array([int(p.majiter) for p in probs]),
-            status=np.array([int(p.mode) for p in probs]), rounds=rounds, n_eval=n_eval, n_eval_fd=n_eval_fd)
+            status=np.array([int(p.mode) for p in probs]), rounds=rounds, n_eval=n_eval, n_eval_fd=n_eval_fd,
+            t_core=t_core, t_serve=t_serve)
 
 
 def _gather(sc: ScenarioBatch, idx: np.ndarray, device) -> ScenarioBatch:
@@ -180,9 +166,11 @@ class BatchedMPC:
     """N controllers ticking together: the batched equivalent of ``URMPC.compute_control``
     (ur_mpc.py:83-247) including the early exit, the DLS start, warm start, output EMA and clip."""
 
-    def __init__(self, ctx: MpcContext):
+    def __init__(self, ctx: MpcContext, solver=None):
+        """`solver`: anything with ``solve(ScenarioBatch, x0) -> BatchSolveResult`` on this context
+        (default: the in-process BatchedSLSQP; pass a ``mpc_amd.pool.SolverPool`` to use more cores)."""
         self.ctx = ctx
-        self.solver = BatchedSLSQP(ctx)
+        self.solver = solver if solver is not None else BatchedSLSQP(ctx)
         self.previous_solution: Optional[np.ndarray] = None   # [N, n], NaN rows = no solution yet
         self.previous_control: Optional[np.ndarray] = None    # [N, 6], NaN rows = attribute absent
         self.last: Optional[BatchSolveResult] = None

@@ -183,6 +183,15 @@ def test_full_size_properties_65536_angular():
     perm = torch.randperm(N, device=ctx.device, generator=torch.Generator(device=ctx.device).manual_seed(1))
     from mpc_amd.solver import _gather
     scp = _gather(sc, perm.cpu().numpy(), ctx.device)
+    from mpc_amd.batch import ScenarioBatch
+    scg = ctx.gather(sc, perm.to(torch.int32), ScenarioBatch.empty(ctx.device, N, 20, True))     # library gather
+    for a, b in ((scg.state0, scp.state0), (scg.target, scp.target), (scg.base_traj, scp.base_traj), (scg.Jc, scp.Jc),
+                 (scg.u_prev, scp.u_prev), (scg.has_prev, scp.has_prev)):
+        assert torch.equal(a, b)
+    bad = ctx.gather(sc, torch.tensor([5, -1, N, 7], dtype=torch.int32, device=ctx.device),
+                     ScenarioBatch.empty(ctx.device, 4, 20, True))
+    assert torch.equal(bad.state0[0], sc.state0[5]) and torch.equal(bad.base_traj[3], sc.base_traj[7])
+    assert bool(torch.isnan(bad.state0[1:3]).all()) and bool(torch.isnan(bad.base_traj[1:3]).all())
     rp = ctx.eval_fd(scp, x[perm].contiguous(), want_jac=False)
     assert torch.equal(rp.cost, cost[perm]) and torch.equal(rp.grad, grad[perm]) and torch.equal(rp.con, con[perm])
     h = N // 2

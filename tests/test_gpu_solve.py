@@ -148,3 +148,30 @@ def test_closed_loop_trajectory_matches_reference_path(motion, H):
             q = q + u * mp.dt
             ee = fk(q, platform_state(motion, hs.amplitude[i], hs.phase[i], (t + 1) * mp.dt))
             np.testing.assert_allclose(got.q[t + 1, i], q, rtol=0, atol=SOL_ATOL)
+
+
+def test_solver_pool_equals_single_process():
+    """Worker processes running the SLSQP cores, this process serving their evaluations from the GPU:
+    same iterates, exit modes and iteration counts as the one-process batch, row for row."""
+    from helpers import host_scenarios
+    from mpc_amd.batch import MpcContext
+    from mpc_amd.pool import SolverPool
+    from mpc_amd.scenarios import to_device
+    from mpc_amd.solver import BatchedSLSQP
+
+    mp = MpcParams.reference_yaml_defaults(horizon=3)
+    ctx = MpcContext(mp, 64, 0)
+    with SolverPool(ctx, workers=3, capacity=40) as pool:
+        for count, with_prev in ((21, False), (40, True), (2, False)):      # 2 scenarios: one worker idle
+            _, hs = host_scenarios(mp, count, motion="linear", cfg_id=8, with_prev=with_prev)
+            sc, _ = to_device(ctx, hs)
+            one = BatchedSLSQP(ctx).solve(sc, hs.x)
+            many = pool.solve(sc, hs.x)
+            np.testing.assert_array_equal(many.x, one.x)
+            np.testing.assert_array_equal(many.status, one.status)
+            np.testing.assert_array_equal(many.nit, one.nit)
+            np.testing.assert_array_equal(many.fun, one.fun)
+            assert many.n_eval == one.n_eval and many.n_eval_fd == one.n_eval_fd
+        with pytest.raises(ValueError):
+            _, hs = host_scenarios(mp, 41, motion="linear", cfg_id=8)
+            pool.solve(to_device(ctx, hs)[0], hs.x)
