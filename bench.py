@@ -52,7 +52,7 @@ def cpu_baseline(mp: MpcParams, hs, budget_s: float = 12.0):
     reference) timed on one host core on a bounded sample of the same scenarios; the C port of the
     same path is timed beside it.  The oracle is only the baseline here, never the product."""
     from oracle.numpy_ref import NumpyRefMPC, base_traj_from_array
-    from oracle.oracle import COracle, ref_params_from
+    from oracle.oracle import COracle, OracleKinematics as _OracleKin, ref_params_from
 
     rp = ref_params_from(mp)
     t0 = time.perf_counter()
@@ -70,7 +70,21 @@ def cpu_baseline(mp: MpcParams, hs, budget_s: float = 12.0):
     t1 = time.perf_counter()
     co.eval_fd(hs.as_oracle_dict(0, nC))
     t_c = time.perf_counter() - t1
+    # one full solve of the reference-shaped path (scipy minimize over the numpy callables), configs[2] shape
+    ha = make_scenarios(mp, _OracleKin(co), 1, motion="angular", cfg_id=3, goal_jitter=0.0)
+    ref = NumpyRefMPC(rp)
+    info = {}
+    t2 = time.perf_counter()
+    ref.compute_control({"position": ha.q0[0], "velocity": np.zeros(6)},
+                        {"position": ha.state0[0, 12:15], "orientation": ha.state0[0, 15:18]},
+                        {"position": ha.target[0, :3], "orientation": ha.target[0, 3:]},
+                        {"position": ha.base[0, 0:3], "orientation": ha.base[0, 3:6], "linear_velocity": ha.base[0, 6:9],
+                         "angular_velocity": ha.base[0, 9:12]}, info=info)
+    t_solve = time.perf_counter() - t2
     return {
+        "solves_value": 1.0 / t_solve, "solves_unit": "solves/s", "solves_sample": f"1 angular-motion scenario, "
+        f"scipy minimize(SLSQP) over the numpy callables, {info.get('nit')} iterations, {info.get('nfev')} cost calls, "
+        f"{t_solve:.1f} s, single thread",
         "value": done / t_np, "unit": "evals/s", "cores": 1, "kind": "port",
         "sample": f"{done} scenarios of the same batch, numpy restatement of ur_mpc.py with scipy approx_derivative "
                   f"(1+n cost rollouts + 1+n constraint rollouts per eval), single thread, {t_np:.1f} s",
@@ -94,26 +108,63 @@ def measured_traffic(H, S, algo):
     return None, None
 
 
-def solve_rate(ctx, mp, count):
+def solve_rate(ctx, mp, per_worker, workers, rank, world, dist):
     """MPC solves/s on a bounded sample (BASELINE.json's second metric): full SLSQP solves of
-    angular-motion scenarios (configs[2] shape) through the lock-step driver.  The quadratic
-    subproblems run in scipy's compiled core on ONE host core, so this rate is host-bound."""
+    angular-motion scenarios (configs[2] shape), one tick each.  Evaluations run on the GPU; the
+    quadratic subproblems run in scipy's compiled core in `workers` host processes per GPU
+    (mpc_amd/pool.py), so this rate is host-bound and scales with host cores, not with the GPU.
+    Every rank calls this; a rank that fails reports it and all ranks skip together (no hang)."""
+    from mpc_amd.pool import SolverPool
     from mpc_amd.solver import BatchedMPC
 
-    if count <= 0:
-        return None
-    hs = make_scenarios(mp, DeviceKinematics(ctx), count, motion="angular", cfg_id=3, goal_jitter=0.0)
-    bm = BatchedMPC(ctx)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    bm.compute_control(hs.q0, hs.state0[:, 12:18], hs.target, hs.base)
-    dt = time.perf_counter() - t0
+    def all_ok(ok):
+        if dist is None:
+            return ok
+        t = torch.tensor([1.0 if ok else 0.0], dtype=torch.float64, device=ctx.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)       # doubles as the barrier before the timed part
+        return bool(t.item() > 0.5)
+
+    count = per_worker * workers
+    pool, err, hs, bm, dt = None, None, None, None, 0.0
+    try:
+        hs = make_scenarios(mp, DeviceKinematics(ctx), count, motion="angular", cfg_id=3, goal_jitter=0.0,
+                            first=rank * count)
+        pool = SolverPool(ctx, workers, capacity=count)
+        warm = min(count, workers)
+        BatchedMPC(ctx, solver=pool).compute_control(hs.q0[:warm], hs.state0[:warm, 12:18], hs.target[:warm], hs.base[:warm])
+        torch.cuda.synchronize()
+    except Exception as exc:  # noqa: BLE001 - the evals/s line must survive a host-side problem
+        err = repr(exc)
+    try:
+        if not all_ok(err is None):
+            return {"error": err or "another rank failed to start its solver pool"}
+        try:
+            bm = BatchedMPC(ctx, solver=pool)
+            t0 = time.perf_counter()
+            bm.compute_control(hs.q0, hs.state0[:, 12:18], hs.target, hs.base)
+            dt = time.perf_counter() - t0
+        except Exception as exc:  # noqa: BLE001
+            err = repr(exc)
+        if not all_ok(err is None):
+            return {"error": err or "another rank failed during its solves"}
+    finally:
+        if pool is not None:
+            pool.close()
     r = bm.last
-    return {"value": int(hs.active.sum()) / dt, "unit": "solves/s", "sample": f"{count} angular-motion scenarios, H={mp.horizon}, "
-            f"one tick each, {int(r.success.sum())} converged, {r.rounds} lock-step rounds, "
-            f"{r.n_eval_fd} eval_fd + {r.n_eval} eval scenario-evals on the GPU, SLSQP core on 1 host core",
-            "host_bound": True, "seconds": dt, "mean_iterations": float(r.nit.mean()),
-            "seconds_in_slsqp_core": r.t_core, "seconds_in_device_calls_and_copies": r.t_serve}
+    stats = torch.tensor([dt, float(hs.active.sum()), float(r.success.sum()), float(r.n_eval_fd), float(r.n_eval)],
+                         dtype=torch.float64, device=ctx.device)
+    if dist is not None:
+        mx = stats.clone()
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        dist.all_reduce(stats, op=dist.ReduceOp.SUM)
+        stats[0] = mx[0]
+    dt_all, solved, conv, nfd, nf = (float(v) for v in stats.tolist())
+    return {"value": solved / dt_all, "unit": "solves/s", "host_bound": True, "host_processes_per_gpu": workers,
+            "sample": f"{int(solved)} angular-motion scenarios ({count} per GPU), H={mp.horizon}, one tick each, "
+                      f"{int(conv)} converged, {int(nfd)} eval_fd + {int(nf)} eval scenario-evals on the GPU, SLSQP cores in "
+                      f"{workers} worker processes per GPU",
+            "seconds": dt_all, "mean_iterations": float(r.nit.mean()), "rounds_rank0": r.rounds,
+            "rank0_max_seconds_in_slsqp_core_per_worker": r.t_core, "rank0_seconds_server_busy": r.t_serve}
 
 
 def main():
@@ -126,7 +177,9 @@ def main():
     ap.add_argument("--motion", default="linear", choices=["linear", "angular"])
     ap.add_argument("--algo", type=int, default=_ffi.ALGO_AUTO)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--solve-sample", type=int, default=96, help="scenarios in the bounded solves/s sample")
+    ap.add_argument("--solve-sample", type=int, default=64,
+                    help="scenarios per worker process in the bounded solves/s sample (0: skip)")
+    ap.add_argument("--solve-workers", type=int, default=0, help="SLSQP worker processes per GPU (0: host cores - 1)")
     ap.add_argument("--only-main", action="store_true",
                     help="run only the timed loop (profiling: every dispatch of the kernel is the benchmark's)")
     args = ap.parse_args()
@@ -187,6 +240,14 @@ def main():
     if gathered is not None:
         assert torch.equal(gathered[rank * S:(rank + 1) * S], out.cost)
 
+    solves = None
+    if not args.only_main and args.solve_sample > 0:        # every rank takes part: one pool per GPU
+        from mpc_amd.pool import host_core_budget
+
+        local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+        workers = args.solve_workers or max(1, min(15, host_core_budget() // max(1, local_world) - 1))
+        solves = solve_rate(ctx, mp, args.solve_sample, workers, rank, world, dist)
+
     if rank == 0:
         total_evals = world * S * args.steps
         value = total_evals / elapsed
@@ -240,8 +301,8 @@ def main():
             e1.record()
             torch.cuda.synchronize()
             line["evals_per_s_4096_scenarios"] = 4096 / (e0.elapsed_time(e1) / args.steps * 1e-3)
-        if extras and world == 1:
-            line["solves"] = solve_rate(ctx, mp, args.solve_sample)
+        if solves is not None:
+            line["solves"] = solves
         if extras and not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(mp, hs)
             line["speedup_vs_cpu_core"] = value / world / line["cpu_baseline"]["value"]

@@ -31,6 +31,25 @@ from .slsqp_state import SharedViews, require_core, worker_main
 from .solver import BatchSolveResult
 
 
+def host_core_budget() -> int:
+    """Cores this process may use: the smallest of its CPU affinity, its cgroup CPU quota and the
+    OMP_NUM_THREADS hint the launcher exports (os.cpu_count() sees the whole machine in a container)."""
+    import os
+
+    budget = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            budget = min(budget, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    try:
+        budget = min(budget, int(os.environ["OMP_NUM_THREADS"]))
+    except (KeyError, ValueError):
+        pass
+    return max(1, budget)
+
+
 def _host_register(ptr: int, nbytes: int) -> bool:
     import ctypes
 
