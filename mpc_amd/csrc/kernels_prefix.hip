@@ -496,34 +496,43 @@ __global__ __launch_bounds__(MAXT) void prefix_kernel(const mpc_params P, const 
     }
 }
 
-// kCompact's second half: one wave per (scenario, step jj) writes the six dense columns of that
+// kCompact's second half: one workgroup per (scenario, step jj) writes the six dense columns of that
 // step (12(H+1) rows each) from the quotients kCompact left in the workspace.  Same row ownership
-// as phase 3 of the fused kernel: per pass a lane owns rows (t, t+1) of state kk.
-__global__ __launch_bounds__(64) void expand_kernel(int H, int count, const double *__restrict__ compact, int cstride,
-                                                    double *__restrict__ jac)
+// as phase 3 of the fused kernel: a lane owns rows (t, t+1) of state kk.
+constexpr int kExpandThreads = 384;      // 768 doubles per pass = 64 states of 12 rows: a lane's row type never changes
+
+__global__ __launch_bounds__(kExpandThreads) void expand_kernel(int H, int count, const double *__restrict__ compact,
+                                                                int cstride, double *__restrict__ jac)
 {
+    // One workgroup per (scenario, step jj): the six columns 6jj..6jj+5 are one contiguous run of 6m
+    // doubles, written front to back, 16 B per lane and 6 KB per workgroup pass (a plain streaming fill).
     typedef double v2d __attribute__((ext_vector_type(2)));
-    const int n = 6 * H, m = 12 * (H + 1);
+    const int n = 6 * H, m = 12 * (H + 1), span = 6 * m, H1 = H + 1;
     const unsigned bid = mpck::xcd_remap(blockIdx.x, gridDim.x);
     const int s = bid / H, jj = bid - s * H;
     if (s >= count) return;
-    const int lane = threadIdx.x;
     const double *cz = compact + (size_t)s * cstride;
     double *out = jac + ((size_t)s * n + 6 * jj) * m;
     const int tj = jj * H - (jj * (jj - 1)) / 2 - jj - 1;
-    for (int r0 = 2 * lane; r0 < m; r0 += 128) {
-        const int kk = r0 / 12, g = (r0 - 12 * kk) >> 1;
-        const bool is_pos = g < 3;
-        const int gp = is_pos ? g : g - 3;
-        const bool hot = is_pos ? (kk > jj) : (kk == jj + 1);
-        v2d val = {0.0, 0.0};
-        if (hot) val = *reinterpret_cast<const v2d *>(is_pos ? cz + 6 * H + 6 * (tj + kk) + 2 * gp : cz + 6 * jj + 2 * gp);
-#pragma unroll
-        for (int aa = 0; aa < 6; ++aa) {
-            const bool mine = gp == (aa >> 1);
-            const v2d v = (aa & 1) ? v2d{0.0, mine ? val.y : 0.0} : v2d{mine ? val.x : 0.0, 0.0};
-            *reinterpret_cast<v2d *>(out + (size_t)aa * m + r0) = v;
+    // m is a multiple of 12, so offset e in the run and row r0 agree mod 12: the lane's pair is always
+    // rows (2g, 2g+1) of some state kk of some column aa
+    const int tid = (int)threadIdx.x;
+    const int g = tid % 6;
+    const bool is_pos = g < 3;
+    const int gp = is_pos ? g : g - 3;
+    const double *src = is_pos ? cz + 6 * H + 6 * tj + 2 * gp : cz + 6 * jj + 2 * gp;
+    int aa = 0, kk = tid / 6;                        // column within the run, state within the column
+    while (kk >= H1) { kk -= H1; ++aa; }
+    for (int e = 2 * tid; e < span; e += 2 * kExpandThreads) {
+        const bool hot = (gp == (aa >> 1)) && (is_pos ? (kk > jj) : (kk == jj + 1));
+        v2d v = {0.0, 0.0};
+        if (hot) {
+            const v2d val = *reinterpret_cast<const v2d *>(is_pos ? src + 6 * kk : src);
+            if (aa & 1) v.y = val.y; else v.x = val.x;
         }
+        *reinterpret_cast<v2d *>(out + e) = v;
+        kk += kExpandThreads / 6;
+        while (kk >= H1) { kk -= H1; ++aa; }
     }
 }
 
@@ -597,7 +606,7 @@ size_t prefix_workspace_doubles_per_scenario(const mpc_params &P)
 
 hipError_t launch_prefix(const mpc_params &P, const double *decay, const mpc_scenarios &sc, const double *x,
                          double *cost, double *grad, double *con, double *jac, double *workspace,
-                         size_t workspace_doubles, hipStream_t stream)
+                         size_t workspace_doubles, hipStream_t stream, const PrefixPipeline *pipe)
 {
     if (!prefix_supported(P)) return hipErrorNotSupported;
     const bool fd = grad != nullptr || jac != nullptr;
@@ -617,13 +626,26 @@ hipError_t launch_prefix(const mpc_params &P, const double *decay, const mpc_sce
     // long horizon: scenarios go through the workspace in chunks (kernel A, then the expansion)
     const size_t per = prefix_workspace_doubles_per_scenario(P);
     int chunk = sc.count;
+    bool piped = false;
+    size_t half = 0;
     if (jac != nullptr) {
         if (workspace == nullptr || workspace_doubles < per) return hipErrorInvalidValue;
-        const size_t fit = workspace_doubles / per;
+        // two halves of the workspace alternate, so that chunk i+1's rollouts (compute-bound, on `stream`)
+        // overlap chunk i's expansion (store-bound, on pipe->aux)
+        piped = pipe != nullptr && pipe->aux != nullptr && workspace_doubles / 2 >= per && sc.count >= 2048;
+        half = piped ? workspace_doubles / 2 : workspace_doubles;
+        const size_t fit = half / per;
         if (fit < (size_t)chunk) chunk = (int)fit;
+        if (piped) {
+            const int quarter = (sc.count + 3) / 4;
+            const int want = quarter > 1024 ? quarter : 1024;
+            if (want < chunk) chunk = want;
+        }
     }
-    for (int first = 0; first < sc.count; first += chunk) {
+    int used = 0;
+    for (int first = 0, i = 0; first < sc.count; first += chunk, ++i) {
         const int cnt = (sc.count - first < chunk) ? sc.count - first : chunk;
+        const int h = piped ? (i & 1) : 0;
         PrefixArgs B = A;
         B.sc.count = cnt;
         B.sc.state0 += (size_t)first * 18; B.sc.target += (size_t)first * 6;
@@ -634,15 +656,31 @@ hipError_t launch_prefix(const mpc_params &P, const double *decay, const mpc_sce
         if (B.grad) B.grad += (size_t)first * n;
         if (B.con) B.con += (size_t)first * m;
         if (B.jac) B.jac += (size_t)first * n * m;
-        B.compact = workspace; B.cstride = (int)per;
-        hipError_t e = launch_mode<kCompact, 512>(P, B, g, (unsigned)cnt, stream);
+        B.compact = workspace + (size_t)h * half; B.cstride = (int)per;
+        hipError_t e = hipSuccess;
+        if (piped && i >= 2) e = hipStreamWaitEvent(stream, pipe->drained[h], 0);   // half h is free again
+        if (e != hipSuccess) return e;
+        e = launch_mode<kCompact, 512>(P, B, g, (unsigned)cnt, stream);
         if (e != hipSuccess) return e;
         if (jac != nullptr) {
-            hipLaunchKernelGGL(expand_kernel, dim3((unsigned)cnt * (unsigned)H), dim3(64), 0, stream, H, cnt, workspace,
-                               (int)per, B.jac);
+            hipStream_t xs = stream;
+            if (piped) {
+                e = hipEventRecord(pipe->filled[h], stream);
+                if (e == hipSuccess) e = hipStreamWaitEvent(pipe->aux, pipe->filled[h], 0);
+                if (e != hipSuccess) return e;
+                xs = pipe->aux;
+            }
+            hipLaunchKernelGGL(expand_kernel, dim3((unsigned)cnt * (unsigned)H), dim3(kExpandThreads), 0, xs, H, cnt,
+                               B.compact, (int)per, B.jac);
             e = hipGetLastError();
+            if (e == hipSuccess && piped) e = hipEventRecord(pipe->drained[h], pipe->aux);
             if (e != hipSuccess) return e;
+            if (used < h + 1) used = h + 1;
         }
+    }
+    for (int h = 0; piped && h < used; ++h) {   // ordinary stream ordering for whatever the caller enqueues next
+        hipError_t e = hipStreamWaitEvent(stream, pipe->drained[h], 0);
+        if (e != hipSuccess) return e;
     }
     return hipSuccess;
 }

@@ -21,6 +21,7 @@ struct mpc_ctx {
     double *d_fvals = nullptr;  // [max_scenarios][n+1], MPC_ALGO_ROLLOUT only
     double *d_work = nullptr;   // long-horizon MPC_ALGO_PREFIX: FD quotients between its two kernels
     size_t work_doubles = 0;
+    mpck::PrefixPipeline pipe;  // second stream + events: overlaps the two long-horizon kernels
     char err[512] = {0};
 };
 
@@ -123,6 +124,11 @@ void mpc_ctx_destroy(mpc_ctx *ctx)
     if (ctx->d_decay) (void)hipFree(ctx->d_decay);
     if (ctx->d_fvals) (void)hipFree(ctx->d_fvals);
     if (ctx->d_work) (void)hipFree(ctx->d_work);
+    for (int h = 0; h < 2; ++h) {
+        if (ctx->pipe.filled[h]) (void)hipEventDestroy(ctx->pipe.filled[h]);
+        if (ctx->pipe.drained[h]) (void)hipEventDestroy(ctx->pipe.drained[h]);
+    }
+    if (ctx->pipe.aux) (void)hipStreamDestroy(ctx->pipe.aux);
     delete ctx;
 }
 
@@ -164,6 +170,13 @@ int mpc_set_params(mpc_ctx *ctx, const mpc_params *p, const double *decay_host, 
         if (want) MPC_HIP(ctx, hipMalloc(&ctx->d_work, want * sizeof(double)));
         ctx->work_doubles = want;
     }
+    if (want && !ctx->pipe.aux) {
+        MPC_HIP(ctx, hipStreamCreateWithFlags(&ctx->pipe.aux, hipStreamNonBlocking));
+        for (int h = 0; h < 2; ++h) {
+            MPC_HIP(ctx, hipEventCreateWithFlags(&ctx->pipe.filled[h], hipEventDisableTiming));
+            MPC_HIP(ctx, hipEventCreateWithFlags(&ctx->pipe.drained[h], hipEventDisableTiming));
+        }
+    }
     ctx->params = *p;
     ctx->have_params = true;
     return MPC_OK;
@@ -201,7 +214,7 @@ int mpc_eval_fd(mpc_ctx *ctx, const mpc_scenarios *sc, const double *x, double *
     MPC_HIP(ctx, hipSetDevice(ctx->device));
     if (resolve_algo(ctx) == MPC_ALGO_PREFIX) {
         MPC_HIP(ctx, mpck::launch_prefix(ctx->params, ctx->d_decay, *sc, x, cost, grad, con, con_jac, ctx->d_work,
-                                         ctx->work_doubles, st));
+                                         ctx->work_doubles, st, ctx->pipe.aux ? &ctx->pipe : nullptr));
         return MPC_OK;
     }
     const int n = 6 * ctx->horizon;

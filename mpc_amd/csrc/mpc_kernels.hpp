@@ -21,9 +21,17 @@ hipError_t launch_fd_finalize(const mpc_params &P, int N, const double *x, const
 // MPC_ALGO_PREFIX: one workgroup per scenario, shared-prefix perturbed rollouts.
 // `workspace` (device, `workspace_doubles` long) is only used for long horizons; its size per
 // scenario is prefix_workspace_doubles_per_scenario() (0 when the fused kernel serves P).
+// `pipe` (optional) lets the long-horizon path run the expansion of one chunk of scenarios on a
+// second stream while the next chunk's rollouts run on `stream`; `stream` waits for the last
+// expansion before launch_prefix returns, so callers see ordinary stream ordering.
+struct PrefixPipeline {
+    hipStream_t aux = nullptr;
+    hipEvent_t filled[2] = {nullptr, nullptr};    // half h of the workspace holds a chunk's quotients
+    hipEvent_t drained[2] = {nullptr, nullptr};   // the expansion has finished reading half h
+};
 hipError_t launch_prefix(const mpc_params &P, const double *decay, const mpc_scenarios &sc, const double *x,
                          double *cost, double *grad, double *con, double *jac, double *workspace,
-                         size_t workspace_doubles, hipStream_t stream);
+                         size_t workspace_doubles, hipStream_t stream, const PrefixPipeline *pipe = nullptr);
 bool prefix_supported(const mpc_params &P);
 size_t prefix_workspace_doubles_per_scenario(const mpc_params &P);
 

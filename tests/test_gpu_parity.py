@@ -238,3 +238,33 @@ def test_h100_batch_in_chunks_equals_one_pass():
     assert_cost_close(full.cost.cpu().numpy()[idx], c_o)
     assert_grad_close(full.grad.cpu().numpy()[idx], g_o)
     np.testing.assert_allclose(full.con_jac.cpu().numpy()[idx], jac_o, rtol=1e-9, atol=1e-10)
+
+
+def test_h100_two_stream_pipeline_equals_plain_chunks():
+    """Batches of >= 2,048 long-horizon scenarios run the expansion of chunk i on a second stream while
+    chunk i+1 rolls out: same bits as 1,024-scenario calls (which take the plain one-stream route),
+    also when two calls follow each other without a sync (the workspace halves are reused in order)."""
+    mp = params_for(100)
+    N = 4096
+    ctx = _ctx(mp, N)
+    co, hs = host_scenarios(mp, N, motion="angular", cfg_id=9)
+    sc, x = to_device(ctx, hs)
+    full = ctx.eval_fd(sc, x)
+    x2 = (x * 0.5).contiguous()
+    again = ctx.eval_fd(sc, x2)            # no sync in between
+    again2 = ctx.eval_fd(sc, x)
+    torch.cuda.synchronize()
+    assert torch.equal(again2.con_jac, full.con_jac) and torch.equal(again2.grad, full.grad)
+    for a in range(0, N, 1024):
+        p = ctx.eval_fd(sc.slice(a, a + 1024), x[a:a + 1024])
+        p2 = ctx.eval_fd(sc.slice(a, a + 1024), x2[a:a + 1024])
+        torch.cuda.synchronize()
+        assert torch.equal(p.con_jac, full.con_jac[a:a + 1024]) and torch.equal(p.grad, full.grad[a:a + 1024])
+        assert torch.equal(p.cost, full.cost[a:a + 1024]) and torch.equal(p.con, full.con[a:a + 1024])
+        assert torch.equal(p2.con_jac, again.con_jac[a:a + 1024]) and torch.equal(p2.cost, again.cost[a:a + 1024])
+    idx = np.array([3, 2047, 2048, 4095])
+    sub = {k: (None if v is None else v[idx]) for k, v in hs.as_oracle_dict().items()}
+    c_o, g_o, con_o, jac_o = co.eval_fd(sub)
+    assert_cost_close(full.cost.cpu().numpy()[idx], c_o)
+    assert_grad_close(full.grad.cpu().numpy()[idx], g_o)
+    np.testing.assert_allclose(full.con_jac[torch.as_tensor(idx, device=ctx.device)].cpu().numpy(), jac_o, rtol=1e-9, atol=1e-10)
