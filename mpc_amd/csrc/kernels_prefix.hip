@@ -499,13 +499,19 @@ __global__ __launch_bounds__(MAXT) void prefix_kernel(const mpc_params P, const 
 // kCompact's second half: one workgroup per (scenario, step jj) writes the six dense columns of that
 // step (12(H+1) rows each) from the quotients kCompact left in the workspace.  Same row ownership
 // as phase 3 of the fused kernel: a lane owns rows (t, t+1) of state kk.
-constexpr int kExpandThreads = 384;      // 768 doubles per pass = 64 states of 12 rows: a lane's row type never changes
+#ifndef MPC_PIPE_CHUNKS
+#define MPC_PIPE_CHUNKS 16         // chunks a large long-horizon batch is pipelined in
+#endif
+#ifndef MPC_EXPAND_THREADS
+#define MPC_EXPAND_THREADS 256   // 6-wave workgroups fill measurably slower than 4- or 8-wave ones (tools/fill_bw.hip)
+#endif
+constexpr int kExpandThreads = MPC_EXPAND_THREADS;
 
 __global__ __launch_bounds__(kExpandThreads) void expand_kernel(int H, int count, const double *__restrict__ compact,
                                                                 int cstride, double *__restrict__ jac)
 {
     // One workgroup per (scenario, step jj): the six columns 6jj..6jj+5 are one contiguous run of 6m
-    // doubles, written front to back, 16 B per lane and 6 KB per workgroup pass (a plain streaming fill).
+    // doubles, written front to back, 16 B per lane and 4 KB per workgroup pass (a plain streaming fill).
     typedef double v2d __attribute__((ext_vector_type(2)));
     const int n = 6 * H, m = 12 * (H + 1), span = 6 * m, H1 = H + 1;
     const unsigned bid = mpck::xcd_remap(blockIdx.x, gridDim.x);
@@ -513,25 +519,26 @@ __global__ __launch_bounds__(kExpandThreads) void expand_kernel(int H, int count
     if (s >= count) return;
     const double *cz = compact + (size_t)s * cstride;
     double *out = jac + ((size_t)s * n + 6 * jj) * m;
-    const int tj = jj * H - (jj * (jj - 1)) / 2 - jj - 1;
-    // m is a multiple of 12, so offset e in the run and row r0 agree mod 12: the lane's pair is always
-    // rows (2g, 2g+1) of some state kk of some column aa
+    const double *pos = cz + 6 * H + 6 * (jj * H - (jj * (jj - 1)) / 2 - jj - 1);
+    const double *vel = cz + 6 * jj;
+    // m is a multiple of 12, so pair p of the run is rows (2g, 2g+1), g = p % 6, of state p / 6 counted
+    // through the six columns; both are advanced incrementally (256 = 42 * 6 + 4)
     const int tid = (int)threadIdx.x;
-    const int g = tid % 6;
-    const bool is_pos = g < 3;
-    const int gp = is_pos ? g : g - 3;
-    const double *src = is_pos ? cz + 6 * H + 6 * tj + 2 * gp : cz + 6 * jj + 2 * gp;
-    int aa = 0, kk = tid / 6;                        // column within the run, state within the column
+    int g = tid % 6, kk = tid / 6, aa = 0;          // row pair, state within the column, column within the run
     while (kk >= H1) { kk -= H1; ++aa; }
     for (int e = 2 * tid; e < span; e += 2 * kExpandThreads) {
+        const bool is_pos = g < 3;
+        const int gp = is_pos ? g : g - 3;
         const bool hot = (gp == (aa >> 1)) && (is_pos ? (kk > jj) : (kk == jj + 1));
         v2d v = {0.0, 0.0};
         if (hot) {
-            const v2d val = *reinterpret_cast<const v2d *>(is_pos ? src + 6 * kk : src);
+            const v2d val = *reinterpret_cast<const v2d *>(is_pos ? pos + 6 * kk + 2 * gp : vel + 2 * gp);
             if (aa & 1) v.y = val.y; else v.x = val.x;
         }
         *reinterpret_cast<v2d *>(out + e) = v;
+        g += kExpandThreads % 6;
         kk += kExpandThreads / 6;
+        if (g >= 6) { g -= 6; ++kk; }
         while (kk >= H1) { kk -= H1; ++aa; }
     }
 }
@@ -637,7 +644,7 @@ hipError_t launch_prefix(const mpc_params &P, const double *decay, const mpc_sce
         const size_t fit = half / per;
         if (fit < (size_t)chunk) chunk = (int)fit;
         if (piped) {
-            const int quarter = (sc.count + 3) / 4;
+            const int quarter = (sc.count + MPC_PIPE_CHUNKS - 1) / MPC_PIPE_CHUNKS;
             const int want = quarter > 1024 ? quarter : 1024;
             if (want < chunk) chunk = want;
         }
