@@ -36,6 +36,33 @@ HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 FP64_VALU_PEAK_TF = 78.6     # 256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz
 
 
+def log(msg):
+    """Progress on stderr when MPC_BENCH_VERBOSE is set (stdout carries only the JSON line)."""
+    if os.environ.get("MPC_BENCH_VERBOSE"):
+        print(f"[bench rank {os.environ.get('RANK', '0')} {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
+_HOST_COLLECTIVES = False    # --rehearse-on-one-gpu: gloo, tensors staged through the host
+
+
+def all_reduce(dist, t, op):
+    if _HOST_COLLECTIVES:
+        h = t.cpu()
+        dist.all_reduce(h, op=op)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, op=op)
+
+
+def all_gather(dist, out, t):
+    if _HOST_COLLECTIVES:
+        h = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_gather_into_tensor(h, t.cpu())
+        out.copy_(h)
+    else:
+        dist.all_gather_into_tensor(out, t)
+
+
 def algorithmic_flops(H: int) -> float:
     """full rollouts, one fused cost+constraint rollout per perturbation."""
     return (1 + 6 * H) * (745 * H + 600 + 30 * (H + 1))
@@ -121,7 +148,7 @@ def solve_rate(ctx, mp, per_worker, workers, rank, world, dist):
         if dist is None:
             return ok
         t = torch.tensor([1.0 if ok else 0.0], dtype=torch.float64, device=ctx.device)
-        dist.all_reduce(t, op=dist.ReduceOp.MIN)       # doubles as the barrier before the timed part
+        all_reduce(dist, t, dist.ReduceOp.MIN)       # doubles as the barrier before the timed part
         return bool(t.item() > 0.5)
 
     count = per_worker * workers
@@ -130,12 +157,14 @@ def solve_rate(ctx, mp, per_worker, workers, rank, world, dist):
         hs = make_scenarios(mp, DeviceKinematics(ctx), count, motion="angular", cfg_id=3, goal_jitter=0.0,
                             first=rank * count)
         pool = SolverPool(ctx, workers, capacity=count)
+        log("pool up")
         warm = min(count, workers)
         BatchedMPC(ctx, solver=pool).compute_control(hs.q0[:warm], hs.state0[:warm, 12:18], hs.target[:warm], hs.base[:warm])
         torch.cuda.synchronize()
     except Exception as exc:  # noqa: BLE001 - the evals/s line must survive a host-side problem
         err = repr(exc)
     try:
+        log(f"pool warm, err={err}")
         if not all_ok(err is None):
             return {"error": err or "another rank failed to start its solver pool"}
         try:
@@ -155,8 +184,8 @@ def solve_rate(ctx, mp, per_worker, workers, rank, world, dist):
                          dtype=torch.float64, device=ctx.device)
     if dist is not None:
         mx = stats.clone()
-        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
-        dist.all_reduce(stats, op=dist.ReduceOp.SUM)
+        all_reduce(dist, mx, dist.ReduceOp.MAX)
+        all_reduce(dist, stats, dist.ReduceOp.SUM)
         stats[0] = mx[0]
     dt_all, solved, conv, nfd, nf = (float(v) for v in stats.tolist())
     return {"value": solved / dt_all, "unit": "solves/s", "host_bound": True, "host_processes_per_gpu": workers,
@@ -180,6 +209,9 @@ def main():
     ap.add_argument("--solve-sample", type=int, default=64,
                     help="scenarios per worker process in the bounded solves/s sample (0: skip)")
     ap.add_argument("--solve-workers", type=int, default=0, help="SLSQP worker processes per GPU (0: host cores - 1)")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="development only: every rank uses device 0 and the process group is gloo, to walk the "
+                         "multi-rank code path on a one-GPU box (the numbers mean nothing)")
     ap.add_argument("--only-main", action="store_true",
                     help="run only the timed loop (profiling: every dispatch of the kernel is the benchmark's)")
     args = ap.parse_args()
@@ -189,13 +221,21 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU: mpc_amd has no CPU path")
+    if args.rehearse_on_one_gpu:
+        global _HOST_COLLECTIVES
+        _HOST_COLLECTIVES = True
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
 
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.rehearse_on_one_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
+    log("process group up")
     H, S = args.horizon, args.scenarios
     mp = MpcParams.reference_yaml_defaults(horizon=H, algo=args.algo)
     ctx = MpcContext(mp, max_scenarios=S, device=local_rank)
@@ -208,9 +248,11 @@ def main():
     def step():
         ctx.eval_fd(sc, x, out=out)
 
+    log("scenarios resident")
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
+    log("warm")
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
@@ -223,16 +265,17 @@ def main():
     gathered = None
     if dist is not None:               # the one exchange of the job: per-scenario results to every rank
         gathered = torch.empty(world * S, dtype=torch.float64, device=ctx.device)
-        dist.all_gather_into_tensor(gathered, out.cost)
+        all_gather(dist, gathered, out.cost)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    log("timed loop done")
     kernel_ms = ev0.elapsed_time(ev1) / args.steps
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=ctx.device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        all_reduce(dist, t, dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
     # sanity: the timed outputs are finite and the gather is the concatenation of the shards
@@ -245,8 +288,10 @@ def main():
         from mpc_amd.pool import host_core_budget
 
         local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
-        workers = args.solve_workers or max(1, min(15, host_core_budget() // max(1, local_world) - 1))
+        workers = args.solve_workers or max(1, min(15, host_core_budget(local_world) - 1))
+        log(f"solves leg: {workers} workers")
         solves = solve_rate(ctx, mp, args.solve_sample, workers, rank, world, dist)
+        log("solves leg done")
 
     if rank == 0:
         total_evals = world * S * args.steps

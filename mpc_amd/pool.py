@@ -31,18 +31,20 @@ from .slsqp_state import SharedViews, require_core, worker_main
 from .solver import BatchSolveResult
 
 
-def host_core_budget() -> int:
-    """Cores this process may use: the smallest of its CPU affinity, its cgroup CPU quota and the
-    OMP_NUM_THREADS hint the launcher exports (os.cpu_count() sees the whole machine in a container)."""
+def host_core_budget(local_world: int = 1) -> int:
+    """Cores one rank may use.  The CPU affinity and the cgroup CPU quota bound the whole job and
+    are shared by the `local_world` ranks of this host; OMP_NUM_THREADS is the launcher's per-process
+    hint.  (os.cpu_count() sees the whole machine in a container and is not used.)"""
     import os
 
-    budget = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    job = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     try:
         quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
         if quota != "max":
-            budget = min(budget, max(1, int(int(quota) / int(period))))
+            job = min(job, max(1, int(int(quota) / int(period))))
     except (OSError, ValueError):
         pass
+    budget = job // max(1, local_world)
     try:
         budget = min(budget, int(os.environ["OMP_NUM_THREADS"]))
     except (KeyError, ValueError):
