@@ -2,6 +2,8 @@
 # usage: tools_pmc.sh <outdir> <prog args...>   -- runs the counter passes one by one
 set -e
 export TMPDIR=/tmp
+R=${GRAFT_REPO_ROOT:-$PWD}
+cd /tmp
 out=$1; shift
 mkdir -p $out
 i=0
@@ -13,7 +15,7 @@ for set in \
  "GRBM_GUI_ACTIVE SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INST_CYCLES_VMEM_WR SQ_THREAD_CYCLES_VALU SQ_INSTS_VALU_INT32 SQ_ACTIVE_INST_VMEM"
 do
   i=$((i+1))
-  timeout -s KILL 120 rocprofv3 --pmc $set --output-format csv -d $out/pass$i -- python3 tools/prof.py "$@" > $out/pass$i.log 2>&1 || { echo "pass $i failed"; tail -5 $out/pass$i.log; }
+  timeout -s KILL 120 rocprofv3 --pmc $set --output-format csv -d $out/pass$i -- python3 $R/tools/prof.py "$@" > $out/pass$i.log 2>&1 || { echo "pass $i failed"; tail -5 $out/pass$i.log; exit 1; }
 done
 python3 - "$out" <<'PY'
 import csv, glob, sys, collections

@@ -1,0 +1,21 @@
+#!/bin/bash
+# Runs on the GPU box: the bench line, the kernel-trace summary of the same command and the PMC passes.
+# usage: bash tools/refresh_profiles.sh <outdir under gpurun_out>.  Stops at the first failing step.
+set -e
+R=${GRAFT_REPO_ROOT:-$PWD}
+out=$R/gpurun_out/$1
+mkdir -p $out
+export TMPDIR=/tmp
+cd $R
+timeout -k 10 300 python3 -u bench.py > $out/bench_line.json
+echo "bench done"
+cd /tmp
+timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt_h20 -- python3 $R/bench.py --only-main > $out/bench_line_only_main.json 2> $out/kt_h20.log
+echo "kernel trace H=20 done"
+timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt_h100 -- python3 $R/bench.py --only-main --horizon 100 --scenarios 16384 --steps 10 > $out/bench_line_H100_only_main.json 2> $out/kt_h100.log
+echo "kernel trace H=100 done"
+cd $R
+timeout -k 10 200 python3 -u bench.py --horizon 100 --scenarios 16384 --steps 10 --no-cpu-baseline --solve-sample 0 > $out/bench_line_H100.json
+echo "bench H=100 done"
+bash tools/pmc.sh $out/pmc 20 65536 0 > $out/pmc_summary.txt
+echo "pmc done"
