@@ -334,6 +334,22 @@ def main():
             line["no_dense_jacobian"] = {"evals_per_s": S / (ms_nj * 1e-3), "kernel_ms": ms_nj,
                                      "fp64_tflops_algorithmic": aflops * S / (ms_nj * 1e-3) / 1e12,
                                      "frac_of_fp64_valu_peak": aflops * S / (ms_nj * 1e-3) / 1e12 / FP64_VALU_PEAK_TF}
+        if extras and ctx.nz_supported():
+            # same derivative information with dc/dx in its structured form (include/mpc_amd.h, mpc_eval_fd_nz):
+            # 11 KB instead of 242 KB per eval at H=20, so this figure is bound by the FP64 pipes, not HBM
+            z = ctx.eval_fd_nz(sc, x)
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(args.steps):
+                ctx.eval_fd_nz(sc, x, out=z)
+            e1.record()
+            torch.cuda.synchronize()
+            ms_nz = e0.elapsed_time(e1) / args.steps
+            line["structured_jacobian"] = {"evals_per_s": S / (ms_nz * 1e-3), "kernel_ms": ms_nz,
+                                           "bytes_out_per_eval": 8 * (1 + mp.n + mp.m + ctx.nz_count),
+                                           "fp64_tflops_algorithmic": aflops * S / (ms_nz * 1e-3) / 1e12,
+                                           "frac_of_fp64_valu_peak": aflops * S / (ms_nz * 1e-3) / 1e12 / FP64_VALU_PEAK_TF}
+            del z
         if extras and S > 4096:   # configs[1] of BASELINE.json: 4,096 scenarios on one GPU
             sc4, x4 = sc.slice(0, 4096), x[:4096]
             o4 = EvalResult(out.cost[:4096], out.grad[:4096], out.con[:4096], out.con_jac[:4096])

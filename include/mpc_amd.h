@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MPC_AMD_ABI_VERSION 2
+#define MPC_AMD_ABI_VERSION 3
 #define MPC_MAX_HORIZON 255
 
 typedef enum mpc_status {
@@ -119,6 +119,23 @@ int mpc_eval(mpc_ctx *ctx, const mpc_scenarios *sc, const double *x, double *cos
  *   layout the Fortran core of SLSQP consumes (a(la, n+1), SLSQP:509).  grad/con/con_jac may be NULL. */
 int mpc_eval_fd(mpc_ctx *ctx, const mpc_scenarios *sc, const double *x, double *cost, double *grad,
                 double *con, double *con_jac, void *stream);
+
+/* Structured form of the same forward-difference dc/dx.  Column x_{6j+a} (control of joint a at step j)
+ * only reaches the rows of joint a: the velocity row of state j+1 and the position rows of states
+ * j+1..H (MPC:398-406 over the Euler rollout DYN:101-128); every other entry of the dense matrix is
+ * an exact zero.  con_jac_nz [N][mpc_jacobian_nz_count(H)] holds those quotients:
+ *   nz[6j + a]                  = d c[12(j+1) + 6 + a] / d x[6j + a]            (j = 0..H-1)
+ *   nz[6H + 6 T(j,k) + a]       = d c[12k + a]         / d x[6j + a]            (k = j+1..H),
+ *   T(j,k) = jH - j(j-1)/2 - j - 1 + k   (pairs (j,k) in lexicographic order).
+ * Same numbers as mpc_eval_fd's con_jac, 22x fewer bytes at H=20 (11 KB instead of 242 KB per scenario):
+ * the form a caller that expands on its own side (the batched SLSQP driver) takes across PCIe.
+ * Needs the UR twist pattern in the DH table (MPC_ERR_UNSUPPORTED otherwise).  grad/con may be NULL. */
+int mpc_jacobian_nz_count(int horizon);
+int mpc_eval_fd_nz(mpc_ctx *ctx, const mpc_scenarios *sc, const double *x, double *cost, double *grad,
+                   double *con, double *con_jac_nz, void *stream);
+
+/* con_jac_nz [N][nz] -> dense con_jac [N][n][m] (the layout of mpc_eval_fd), on the device. */
+int mpc_expand_jacobian(mpc_ctx *ctx, int count, const double *con_jac_nz, double *con_jac, void *stream);
 
 /* Batched 6x6 geometric Jacobian, row-major, rows 0-2 linear / 3-5 angular: replaces
  * UR20Dynamics.get_jacobian (DYN:74-87; MoveIt's getJacobian in the reference).  q [N][6] -> J [N][36]. */

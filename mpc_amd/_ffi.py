@@ -11,11 +11,12 @@ LIB_PATH = os.environ.get("MPC_AMD_LIB") or os.path.join(_HERE, "libmpc_amd.so")
 MPC_OK = 0
 ALGO_AUTO, ALGO_ROLLOUT, ALGO_PREFIX = 0, 1, 2
 MAX_HORIZON = 255
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 EXPORTS = (
     "mpc_abi_version", "mpc_ctx_create", "mpc_ctx_destroy", "mpc_set_params", "mpc_eval", "mpc_eval_fd",
-    "mpc_jacobian", "mpc_fk", "mpc_predict_base_dynamic", "mpc_gather_scenarios", "mpc_last_error",
+    "mpc_jacobian", "mpc_fk", "mpc_predict_base_dynamic", "mpc_gather_scenarios", "mpc_jacobian_nz_count", "mpc_eval_fd_nz",
+    "mpc_expand_jacobian", "mpc_last_error",
 )
 
 
@@ -82,6 +83,12 @@ def load():
     L.mpc_predict_base_dynamic.argtypes = [vp, ip, vp, dp, vp, vp]
     L.mpc_gather_scenarios.restype = ip
     L.mpc_gather_scenarios.argtypes = [vp, C.POINTER(MpcScenariosC), vp, ip, C.POINTER(MpcScenariosC), vp]
+    L.mpc_jacobian_nz_count.restype = ip
+    L.mpc_jacobian_nz_count.argtypes = [ip]
+    L.mpc_eval_fd_nz.restype = ip
+    L.mpc_eval_fd_nz.argtypes = [vp, C.POINTER(MpcScenariosC), vp, vp, vp, vp, vp, vp]
+    L.mpc_expand_jacobian.restype = ip
+    L.mpc_expand_jacobian.argtypes = [vp, ip, vp, vp, vp]
     L.mpc_last_error.restype = C.c_char_p
     L.mpc_last_error.argtypes = [vp]
     if L.mpc_abi_version() != ABI_VERSION:

@@ -73,6 +73,7 @@ class EvalResult:
     grad: Optional[torch.Tensor]       # [N,n]
     con: Optional[torch.Tensor]        # [N,m]
     con_jac: Optional[torch.Tensor]    # [N,n,m]: per scenario column-major m x n
+    con_jac_nz: Optional[torch.Tensor] = None   # [N, 6H+3H(H+1)]: structured form (eval_fd_nz)
 
     def jac_for_scipy(self, i: int) -> np.ndarray:
         """(m, n) Fortran-ordered array of scenario i, the layout SLSQP's core consumes."""
@@ -179,6 +180,43 @@ class MpcContext:
         _ffi.check(self._ctx, self._lib.mpc_eval_fd(self._ctx, C.byref(scc), xp, cost.data_ptr(), gp, cp, jp,
                                                     self._stream()))
         return EvalResult(cost, grad, con, jac)
+
+    @property
+    def nz_count(self) -> int:
+        return int(self._lib.mpc_jacobian_nz_count(self.H))
+
+    def nz_supported(self) -> bool:
+        """Does this context serve the structured dc/dx (it needs the prefix kernel)?"""
+        empty = _ffi.MpcScenariosC()
+        empty.count = 0
+        return self._lib.mpc_eval_fd_nz(self._ctx, C.byref(empty), None, None, None, None, None, None) == 0
+
+    def eval_fd_nz(self, sc: ScenarioBatch, x: torch.Tensor, want_grad: bool = True, want_con: bool = True,
+                   out: Optional[EvalResult] = None) -> EvalResult:
+        """Like eval_fd, with dc/dx in its structured form (include/mpc_amd.h): [N, nz_count]."""
+        N = sc.count
+        scc = self._scen_c(sc)
+        xp = self._chk(x, (N, self.n), "x")
+        cost = out.cost if out is not None else self._new(N)
+        grad = (out.grad if out is not None and out.grad is not None else self._new(N, self.n)) if want_grad else None
+        con = (out.con if out is not None and out.con is not None else self._new(N, self.m)) if want_con else None
+        nz = out.con_jac_nz if out is not None and out.con_jac_nz is not None else self._new(N, self.nz_count)
+        self._chk(cost, (N,), "cost")
+        gp = self._chk(grad, (N, self.n), "grad", optional=True)
+        cp = self._chk(con, (N, self.m), "con", optional=True)
+        zp = self._chk(nz, (N, self.nz_count), "con_jac_nz")
+        _ffi.check(self._ctx, self._lib.mpc_eval_fd_nz(self._ctx, C.byref(scc), xp, cost.data_ptr(), gp, cp, zp,
+                                                       self._stream()))
+        return EvalResult(cost, grad, con, None, nz)
+
+    def expand_jacobian(self, nz: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Structured [N, nz_count] -> dense [N, n, m] on the device."""
+        N = int(nz.shape[0])
+        zp = self._chk(nz, (N, self.nz_count), "con_jac_nz")
+        jac = out if out is not None else self._new(N, self.n, self.m)
+        jp = self._chk(jac, (N, self.n, self.m), "con_jac")
+        _ffi.check(self._ctx, self._lib.mpc_expand_jacobian(self._ctx, N, zp, jp, self._stream()))
+        return jac
 
     def gather(self, src: ScenarioBatch, index: torch.Tensor, out: ScenarioBatch) -> ScenarioBatch:
         """Rows ``index`` (int32 device tensor [k], values in [0, src.count)) of ``src`` -> the first k

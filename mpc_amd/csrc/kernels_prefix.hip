@@ -611,6 +611,37 @@ size_t prefix_workspace_doubles_per_scenario(const mpc_params &P)
     return 6 * H + 3 * H * (H + 1);
 }
 
+size_t jacobian_nz_count(int horizon)
+{
+    const size_t H = (size_t)horizon;
+    return 6 * H + 3 * H * (H + 1);
+}
+
+bool prefix_nz_supported(const mpc_params &P) { return ur_pattern(P) && compact_ok(P); }
+
+hipError_t launch_prefix_nz(const mpc_params &P, const double *decay, const mpc_scenarios &sc, const double *x,
+                            double *cost, double *grad, double *con, double *nz, hipStream_t stream)
+{
+    if (!prefix_nz_supported(P) || nz == nullptr) return hipErrorNotSupported;
+    const Geometry g = geometry(P, kCompact);
+    PrefixArgs A;
+    A.decay = decay; A.sc = sc; A.x = x; A.cost = cost; A.grad = grad; A.con = con;
+    A.jac = nz;      // kCompact only tests it against NULL ("the quotients are wanted")
+    A.compact = nz; A.cstride = (int)jacobian_nz_count(P.horizon);
+    A.S = g.S; A.items = g.items;
+    const unsigned grid = (unsigned)((sc.count + g.S - 1) / g.S);
+    return g.threads <= 128 ? launch_mode<kCompact, 128>(P, A, g, grid, stream)
+                            : launch_mode<kCompact, 512>(P, A, g, grid, stream);
+}
+
+hipError_t launch_expand(const mpc_params &P, int count, const double *nz, double *jac, hipStream_t stream)
+{
+    const int H = P.horizon;
+    hipLaunchKernelGGL(expand_kernel, dim3((unsigned)count * (unsigned)H), dim3(kExpandThreads), 0, stream, H, count, nz,
+                       (int)jacobian_nz_count(H), jac);
+    return hipGetLastError();
+}
+
 hipError_t launch_prefix(const mpc_params &P, const double *decay, const mpc_scenarios &sc, const double *x,
                          double *cost, double *grad, double *con, double *jac, double *workspace,
                          size_t workspace_doubles, hipStream_t stream, const PrefixPipeline *pipe)
@@ -618,7 +649,9 @@ hipError_t launch_prefix(const mpc_params &P, const double *decay, const mpc_sce
     if (!prefix_supported(P)) return hipErrorNotSupported;
     const bool fd = grad != nullptr || jac != nullptr;
     const bool fused = fused_ok(P);
-    const int mode = !fd ? kEval : (fused ? kFused : kCompact);
+    // the LDS image of kFused exists for the dense dc/dx; without it the leaner kCompact layout
+    // (no staged quotients) lets more workgroups share a CU
+    const int mode = !fd ? kEval : ((fused && jac != nullptr) ? kFused : kCompact);
     const Geometry g = geometry(P, mode);
     const int H = P.horizon, n = 6 * H, m = 12 * (H + 1);
     PrefixArgs A;
@@ -629,6 +662,11 @@ hipError_t launch_prefix(const mpc_params &P, const double *decay, const mpc_sce
         const unsigned grid = (unsigned)((sc.count + g.S - 1) / g.S);
         if (mode == kEval) return fused ? launch_mode<kEval, 128>(P, A, g, grid, stream) : launch_mode<kEval, 512>(P, A, g, grid, stream);
         return launch_mode<kFused, 128>(P, A, g, grid, stream);
+    }
+    if (jac == nullptr) {   // f, c, grad f only: one launch, nothing staged
+        const unsigned grid = (unsigned)((sc.count + g.S - 1) / g.S);
+        return g.threads <= 128 ? launch_mode<kCompact, 128>(P, A, g, grid, stream)
+                                : launch_mode<kCompact, 512>(P, A, g, grid, stream);
     }
     // long horizon: scenarios go through the workspace in chunks (kernel A, then the expansion)
     const size_t per = prefix_workspace_doubles_per_scenario(P);

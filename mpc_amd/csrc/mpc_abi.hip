@@ -223,6 +223,41 @@ int mpc_eval_fd(mpc_ctx *ctx, const mpc_scenarios *sc, const double *x, double *
     return MPC_OK;
 }
 
+int mpc_jacobian_nz_count(int horizon)
+{
+    return (horizon > 0 && horizon <= MPC_MAX_HORIZON) ? (int)mpck::jacobian_nz_count(horizon) : 0;
+}
+
+int mpc_eval_fd_nz(mpc_ctx *ctx, const mpc_scenarios *sc, const double *x, double *cost, double *grad, double *con,
+                   double *con_jac_nz, void *stream)
+{
+    int rc = check_ready(ctx);
+    if (rc) return rc;
+    if (resolve_algo(ctx) != MPC_ALGO_PREFIX || !mpck::prefix_nz_supported(ctx->params))  // also for an empty batch: a probe
+        return fail(ctx, MPC_ERR_UNSUPPORTED, "the structured dc/dx needs MPC_ALGO_PREFIX (UR twist pattern, H <= 170)");
+    rc = check_scenarios(ctx, sc, x);
+    if (rc) return rc;
+    if (sc->count == 0) return MPC_OK;
+    if (!cost || !con_jac_nz) return fail(ctx, MPC_ERR_INVALID_ARG, "cost / con_jac_nz is NULL");
+    MPC_HIP(ctx, hipSetDevice(ctx->device));
+    MPC_HIP(ctx, mpck::launch_prefix_nz(ctx->params, ctx->d_decay, *sc, x, cost, grad, con, con_jac_nz,
+                                        static_cast<hipStream_t>(stream)));
+    return MPC_OK;
+}
+
+int mpc_expand_jacobian(mpc_ctx *ctx, int count, const double *con_jac_nz, double *con_jac, void *stream)
+{
+    int rc = check_ready(ctx);
+    if (rc) return rc;
+    if (count < 0 || count > ctx->max_scenarios)
+        return fail(ctx, MPC_ERR_INVALID_ARG, "count %d outside [0, %d]", count, ctx->max_scenarios);
+    if (count == 0) return MPC_OK;
+    if (!con_jac_nz || !con_jac) return fail(ctx, MPC_ERR_INVALID_ARG, "con_jac_nz / con_jac is NULL");
+    MPC_HIP(ctx, hipSetDevice(ctx->device));
+    MPC_HIP(ctx, mpck::launch_expand(ctx->params, count, con_jac_nz, con_jac, static_cast<hipStream_t>(stream)));
+    return MPC_OK;
+}
+
 int mpc_jacobian(mpc_ctx *ctx, int count, const double *q, double *J, void *stream)
 {
     int rc = check_ready(ctx);

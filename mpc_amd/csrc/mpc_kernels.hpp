@@ -32,6 +32,12 @@ struct PrefixPipeline {
 hipError_t launch_prefix(const mpc_params &P, const double *decay, const mpc_scenarios &sc, const double *x,
                          double *cost, double *grad, double *con, double *jac, double *workspace,
                          size_t workspace_doubles, hipStream_t stream, const PrefixPipeline *pipe = nullptr);
+// Structured dc/dx (include/mpc_amd.h, mpc_eval_fd_nz): the rollout kernel alone, quotients to `nz`.
+hipError_t launch_prefix_nz(const mpc_params &P, const double *decay, const mpc_scenarios &sc, const double *x,
+                            double *cost, double *grad, double *con, double *nz, hipStream_t stream);
+hipError_t launch_expand(const mpc_params &P, int count, const double *nz, double *jac, hipStream_t stream);
+bool prefix_nz_supported(const mpc_params &P);
+size_t jacobian_nz_count(int horizon);
 bool prefix_supported(const mpc_params &P);
 size_t prefix_workspace_doubles_per_scenario(const mpc_params &P);
 

@@ -81,10 +81,12 @@ class SolverPool:
         n, m = p.n, p.m
         self.lb = np.array([b[0] for b in p.bounds()])
         self.ub = np.array([b[1] for b in p.bounds()])
+        self.structured = ctx.nz_supported()     # dc/dx crosses PCIe in its structured form where the kernel offers it
+        jw = ctx.nz_count if self.structured else n * m
         page = 2 << 20
-        size = (SharedViews.nbytes(cap, n, m) + page - 1) // page * page
+        size = (SharedViews.nbytes(cap, n, m, jw) + page - 1) // page * page
         self._shm = shared_memory.SharedMemory(create=True, size=size)
-        self._v = SharedViews(self._shm.buf, cap, n, m)
+        self._v = SharedViews(self._shm.buf, cap, n, m, jw)
         # page-lock the block so that device -> shared-memory copies are direct DMA; without it the
         # copies still work (the runtime stages them), only slower
         base = np.ndarray((self._shm.size,), dtype=np.uint8, buffer=self._shm.buf)
@@ -96,14 +98,15 @@ class SolverPool:
         dev = ctx.device
         z = lambda *shape: torch.empty(shape, dtype=torch.float64, device=dev)
         self._x_dev = z(cap, n)
-        self._out = EvalResult(z(cap), z(cap, n), z(cap, m), z(cap, n, m))
+        self._out = EvalResult(z(cap), z(cap, n), z(cap, m), None if self.structured else z(cap, n, m),
+                               z(cap, jw) if self.structured else None)
         self._sub = {False: ScenarioBatch.empty(dev, cap, p.horizon, False),
                      True: ScenarioBatch.empty(dev, cap, p.horizon, True)}
         spawn = mp.get_context("spawn")      # workers must not inherit a process that holds the GPU
         self._conns, self._procs = [], []
         for _ in range(workers):
             parent, child = spawn.Pipe()
-            proc = spawn.Process(target=worker_main, args=(child, self._shm.name, cap, n, m), daemon=True)
+            proc = spawn.Process(target=worker_main, args=(child, self._shm.name, cap, n, m, self.structured), daemon=True)
             proc.start()
             child.close()
             self._conns.append(parent)
@@ -126,16 +129,22 @@ class SolverPool:
         self._x_dev[:K].copy_(torch.from_numpy(np.clip(v.X[idx], self.lb, self.ub)))   # _clip_x_for_func
         sub = ctx.gather(sc, idx_dev, self._sub[sc.u_prev is not None])
         o = self._out
-        if need_grad:
+        jac = None
+        if need_grad and self.structured:
+            ctx.eval_fd_nz(sub, self._x_dev[:K], want_con=False,
+                           out=EvalResult(o.cost[:K], o.grad[:K], None, None, o.con_jac_nz[:K]))
+            jac = o.con_jac_nz
+        elif need_grad:
             ctx.eval_fd(sub, self._x_dev[:K], want_con=False,
                         out=EvalResult(o.cost[:K], o.grad[:K], None, o.con_jac[:K]))
+            jac = o.con_jac.view(self.cap, -1)
         else:
             ctx.eval(sub, self._x_dev[:K], out=EvalResult(o.cost[:K], None, o.con[:K], None))
         off = 0
         for f, k in reqs:
             if need_grad:
                 self._t["SG"][f:f + k].copy_(o.grad[off:off + k])
-                self._t["SA"][f:f + k].copy_(o.con_jac[off:off + k])
+                self._t["SJ"][f:f + k].copy_(jac[off:off + k])
             else:
                 self._t["SF"][f:f + k].copy_(o.cost[off:off + k])
                 self._t["SC"][f:f + k].copy_(o.con[off:off + k])
@@ -162,8 +171,13 @@ class SolverPool:
         # mode 0 on entry: f, g, c, a at the start point for everyone (_slsqp_py.py:419-425)
         self._x_dev[:N].copy_(torch.from_numpy(v.X[:N]))
         o = self._out
-        ctx.eval_fd(sc, self._x_dev[:N], out=EvalResult(o.cost[:N], o.grad[:N], o.con[:N], o.con_jac[:N]))
-        for key, src in (("SF", o.cost), ("SC", o.con), ("SG", o.grad), ("SA", o.con_jac)):
+        if self.structured:
+            ctx.eval_fd_nz(sc, self._x_dev[:N], out=EvalResult(o.cost[:N], o.grad[:N], o.con[:N], None, o.con_jac_nz[:N]))
+            jac = o.con_jac_nz
+        else:
+            ctx.eval_fd(sc, self._x_dev[:N], out=EvalResult(o.cost[:N], o.grad[:N], o.con[:N], o.con_jac[:N]))
+            jac = o.con_jac.view(self.cap, -1)
+        for key, src in (("SF", o.cost), ("SC", o.con), ("SG", o.grad), ("SJ", jac)):
             self._t[key][:N].copy_(src[:N])
         n_eval, n_eval_fd = 0, N
         t_serve += time.perf_counter() - t0

@@ -66,6 +66,26 @@ class Problem:
         return md
 
 
+def nz_count(H: int) -> int:
+    return 6 * H + 3 * H * (H + 1)
+
+
+def nz_scatter_index(H: int) -> np.ndarray:
+    """Flat positions, inside one problem's (n+1, m) C-ordered array (= the core's column-major
+    a(la, n+1)), of the entries of the structured dc/dx (include/mpc_amd.h, mpc_eval_fd_nz), in the
+    structured order: ``A.reshape(-1)[nz_scatter_index(H)] = nz`` expands one scenario."""
+    m = 12 * (H + 1)
+    idx = np.empty(nz_count(H), dtype=np.int64)
+    for j in range(H):
+        tri = j * H - (j * (j - 1)) // 2 - j - 1
+        for a in range(6):
+            col = 6 * j + a
+            idx[col] = col * m + 12 * (j + 1) + 6 + a
+            for k in range(j + 1, H + 1):
+                idx[6 * H + 6 * (tri + k) + a] = col * m + 12 * k + a
+    return idx
+
+
 class SharedViews:
     """numpy views of the pool's shared-memory block.  Capacity `cap` scenarios.
 
@@ -73,18 +93,19 @@ class SharedViews:
     SF   [cap]      staged f          worker w reads its k staged rows at [first_w, first_w + k)
     SC   [cap,m]    staged c
     SG   [cap,n]    staged grad f
-    SA   [cap,n,m]  staged dc/dx (column-major m x n per row)
+    SJ   [cap,jw]   staged dc/dx: structured (jw = nz_count(H), include/mpc_amd.h) or dense column-major
+                    m x n (jw = n*m) when the context cannot produce the structured form
     IDXF [cap] i4   scenarios of worker w that want (f, c), listed at [first_w, ...)
     IDXG [cap] i4   scenarios that want (grad f, dc/dx)
     """
 
-    FIELDS = ("X", "SF", "SC", "SG", "SA")
+    FIELDS = ("X", "SF", "SC", "SG", "SJ")
 
     @staticmethod
-    def nbytes(cap, n, m):
-        return 8 * cap * (n + 1 + m + n + n * m) + 2 * 4 * cap
+    def nbytes(cap, n, m, jw):
+        return 8 * cap * (n + 1 + m + n + jw) + 2 * 4 * cap
 
-    def __init__(self, buf, cap, n, m):
+    def __init__(self, buf, cap, n, m, jw):
         off = 0
 
         def take(shape, dtype=np.float64):
@@ -97,19 +118,21 @@ class SharedViews:
         self.SF = take((cap,))
         self.SC = take((cap, m))
         self.SG = take((cap, n))
-        self.SA = take((cap, n, m))
+        self.SJ = take((cap, jw))
         self.IDXF = take((cap,), np.int32)
         self.IDXG = take((cap,), np.int32)
 
 
-def worker_main(conn, shm_name, cap, n, m):
+def worker_main(conn, shm_name, cap, n, m, structured):
     """Pool worker: owns the SLSQP cores of a contiguous range of scenarios.  Never touches the GPU."""
     import time
     from multiprocessing import shared_memory
 
     shm = shared_memory.SharedMemory(name=shm_name)
     try:
-        v = SharedViews(shm.buf, cap, n, m)
+        H = n // 6
+        v = SharedViews(shm.buf, cap, n, m, nz_count(H) if structured else n * m)
+        scatter = nz_scatter_index(H) if structured else None
         conn.send(("ready",))
         while True:
             msg = conn.recv()
@@ -117,7 +140,7 @@ def worker_main(conn, shm_name, cap, n, m):
                 break
             _, first, cnt, acc, maxiter, xl, xu = msg
             try:
-                _solve_range(conn, v, first, cnt, n, m, acc, maxiter, xl, xu, time)
+                _solve_range(conn, v, scatter, first, cnt, n, m, acc, maxiter, xl, xu, time)
             except Exception as exc:  # noqa: BLE001 - reported to the server
                 conn.send(("error", repr(exc)))
         del v
@@ -125,8 +148,9 @@ def worker_main(conn, shm_name, cap, n, m):
         shm.close()
 
 
-def _solve_range(conn, v, first, cnt, n, m, acc, maxiter, xl, xu, time):
+def _solve_range(conn, v, scatter, first, cnt, n, m, acc, maxiter, xl, xu, time):
     A = np.zeros((cnt, n + 1, m))
+    Aflat = A.reshape(cnt, -1)
     probs = [Problem(v.X[first + i], n, m, acc, maxiter, A[i].T) for i in range(cnt)]
     want_f, want_g = [], list(range(cnt))
     initial = True
@@ -144,7 +168,10 @@ def _solve_range(conn, v, first, cnt, n, m, acc, maxiter, xl, xu, time):
             p = probs[i]
             p.g[:n] = v.SG[first + j]
             p.g[n] = 0.0
-            A[i, :n, :] = v.SA[first + j]
+            if scatter is not None:
+                Aflat[i, scatter] = v.SJ[first + j]          # every other entry stays zero
+            else:
+                A[i, :n, :] = v.SJ[first + j].reshape(n, m)
             if initial:                      # mode 0 on entry: f, c, g, a at the start point
                 p.fx = float(v.SF[first + j])
                 p.c[:] = v.SC[first + j]

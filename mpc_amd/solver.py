@@ -26,7 +26,7 @@ import torch
 
 from .batch import EvalResult, MpcContext, ScenarioBatch
 
-from .slsqp_state import EXIT_MESSAGES, Problem, require_core  # noqa: F401
+from .slsqp_state import EXIT_MESSAGES, Problem, nz_scatter_index, require_core  # noqa: F401
 
 
 @dataclass
@@ -65,6 +65,9 @@ class BatchedSLSQP:
             raise ValueError("batch larger than the context")
         X = np.clip(np.array(x0, dtype=np.float64).reshape(N, n), self.lb, self.ub)   # _slsqp_py.py:268
         A = np.zeros((N, n + 1, m))          # A[i].T is the core's a(la, n+1), column-major
+        structured = ctx.nz_supported()      # dc/dx crosses PCIe in its structured form where the kernel offers it
+        Aflat = A.reshape(N, -1)
+        scatter = nz_scatter_index(ctx.params.horizon) if structured else None
         probs: List[Problem] = [Problem(X[i], n, m, ctx.params.ftol, ctx.params.maxiter, A[i].T)
                                  for i in range(N)]
         xl, xu = self.lb.copy(), self.ub.copy()
@@ -93,6 +96,18 @@ class BatchedSLSQP:
             t = tick("gather", t)
             xd = self._to_dev(np.clip(X[idx], self.lb, self.ub))
             t = tick("upload", t)
+            if need_grad and structured:
+                r = ctx.eval_fd_nz(sub, xd)
+                t = tick("kernel", t)
+                g = r.grad.cpu().numpy()
+                nz = r.con_jac_nz.cpu().numpy()
+                t = tick("d2h", t)
+                for k, i in enumerate(idx):
+                    probs[i].g[:n] = g[k]
+                    probs[i].g[n] = 0.0
+                Aflat[np.asarray(idx)[:, None], scatter[None, :]] = nz     # every other entry stays zero
+                tick("scatter", t)
+                return r
             if need_grad:
                 r = ctx.eval_fd(sub, xd)
                 t = tick("kernel", t)

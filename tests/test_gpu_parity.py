@@ -268,3 +268,36 @@ def test_h100_two_stream_pipeline_equals_plain_chunks():
     assert_cost_close(full.cost.cpu().numpy()[idx], c_o)
     assert_grad_close(full.grad.cpu().numpy()[idx], g_o)
     np.testing.assert_allclose(full.con_jac[torch.as_tensor(idx, device=ctx.device)].cpu().numpy(), jac_o, rtol=1e-9, atol=1e-10)
+
+
+@pytest.mark.parametrize("H,N", [(1, 37), (3, 29), (20, 512), (100, 24)])
+def test_structured_jacobian_equals_dense(H, N):
+    """mpc_eval_fd_nz: same f, grad f, c as mpc_eval_fd, and its structured dc/dx expands (on the device with
+    mpc_expand_jacobian, on the host with slsqp_state.nz_scatter_index) to exactly mpc_eval_fd's dense matrix."""
+    from mpc_amd.slsqp_state import nz_count, nz_scatter_index
+
+    mp = params_for(H)
+    ctx = _ctx(mp, N)
+    co, hs = host_scenarios(mp, N, motion="angular", cfg_id=11, with_prev=True, near_bounds=True)
+    sc, x = to_device(ctx, hs)
+    dense = ctx.eval_fd(sc, x)
+    z = ctx.eval_fd_nz(sc, x)
+    torch.cuda.synchronize()
+    assert ctx.nz_count == nz_count(H) and tuple(z.con_jac_nz.shape) == (N, nz_count(H))
+    assert torch.equal(z.cost, dense.cost) and torch.equal(z.grad, dense.grad) and torch.equal(z.con, dense.con)
+    assert torch.equal(ctx.expand_jacobian(z.con_jac_nz), dense.con_jac)
+    idx = nz_scatter_index(H)
+    assert len(np.unique(idx)) == len(idx)
+    nz = z.con_jac_nz.cpu().numpy()
+    want = dense.con_jac.cpu().numpy()
+    for i in (0, N // 2, N - 1):
+        A = np.zeros((mp.n + 1, mp.m))
+        A.reshape(-1)[idx] = nz[i]
+        np.testing.assert_array_equal(A[:mp.n], want[i])
+        assert not A[mp.n].any()
+    # nothing but the listed entries is ever non-zero in the dense matrix
+    mask = np.ones(mp.n * mp.m, bool)
+    mask[idx] = False
+    assert not want.reshape(N, -1)[:, mask].any()
+    only = ctx.eval_fd_nz(sc, x, want_grad=False, want_con=False)
+    assert torch.equal(only.con_jac_nz, z.con_jac_nz) and torch.equal(only.cost, dense.cost)

@@ -5,11 +5,12 @@ import multiprocessing as mp_
 from multiprocessing import connection, shared_memory
 
 import numpy as np
+import pytest
 from scipy.optimize import minimize
 
 from helpers import host_scenarios, params_for
 from mpc_amd.sharding import shard_range
-from mpc_amd.slsqp_state import Problem, SharedViews, worker_main
+from mpc_amd.slsqp_state import Problem, SharedViews, nz_count, nz_scatter_index, worker_main
 
 
 def _row(hs, i, x):
@@ -55,7 +56,9 @@ def test_step_reproduces_scipy_minimize():
         assert p.fx == res.fun
 
 
-def test_worker_protocol_equals_in_process_loop():
+@pytest.mark.parametrize("structured", [False, True])
+def test_worker_protocol_equals_in_process_loop(structured):
+    """Workers fed dense dc/dx, or its structured form (include/mpc_amd.h) which they expand themselves."""
     mp = params_for(3)
     N, W = 7, 3                     # 3 + 2 + 2 scenarios
     co, hs = host_scenarios(mp, N, motion="linear", cfg_id=6)
@@ -64,14 +67,16 @@ def test_worker_protocol_equals_in_process_loop():
     ub = np.array([b[1] for b in mp.bounds()])
     want = [_lockstep_one(co, hs, i, mp, lb, ub) for i in range(N)]
 
-    shm = shared_memory.SharedMemory(create=True, size=SharedViews.nbytes(N, n, m))
+    jw = nz_count(mp.horizon) if structured else n * m
+    pack = (lambda a: a.reshape(-1)[nz_scatter_index(mp.horizon)]) if structured else (lambda a: a.reshape(-1))
+    shm = shared_memory.SharedMemory(create=True, size=SharedViews.nbytes(N, n, m, jw))
     spawn = mp_.get_context("spawn")
     conns, procs = [], []
     try:
-        v = SharedViews(shm.buf, N, n, m)
+        v = SharedViews(shm.buf, N, n, m, jw)
         for _ in range(W):
             a, b = spawn.Pipe()
-            pr = spawn.Process(target=worker_main, args=(b, shm.name, N, n, m), daemon=True)
+            pr = spawn.Process(target=worker_main, args=(b, shm.name, N, n, m, structured), daemon=True)
             pr.start()
             b.close()
             conns.append(a)
@@ -85,7 +90,8 @@ def test_worker_protocol_equals_in_process_loop():
             busy[c] = (first, cnt)
         d = hs.as_oracle_dict()
         d["x"] = v.X.copy()
-        v.SF[:], v.SG[:], v.SC[:], v.SA[:] = co.eval_fd(d)
+        v.SF[:], v.SG[:], v.SC[:], jac0 = co.eval_fd(d)
+        v.SJ[:] = np.stack([pack(a) for a in jac0])
         for c in conns:
             c.send(("data",))
         fun, status = np.zeros(N), np.zeros(N, int)
@@ -104,7 +110,7 @@ def test_worker_protocol_equals_in_process_loop():
                     v.SF[first + j], v.SC[first + j] = f[0], cc[0]
                 for j, s in enumerate(v.IDXG[first:first + kg]):
                     _, g, _, a = co.eval_fd(_row(hs, int(s), np.clip(v.X[s], lb, ub)))
-                    v.SG[first + j], v.SA[first + j] = g[0], a[0]
+                    v.SG[first + j], v.SJ[first + j] = g[0], pack(a[0])
                 c.send(("data",))
         X = v.X.copy()
         del v

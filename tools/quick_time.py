@@ -27,3 +27,22 @@ for want_jac in (True, False):
     ms = e0.elapsed_time(e1) / K
     bytes_out = N * (1 + mp.n + mp.m + (mp.n * mp.m if want_jac else 0)) * 8
     print(f"H={H} N={N} algo={algo} jac={want_jac}: {ms:.3f} ms/step, {N/ms*1e3:.3e} evals/s, out {bytes_out/ms/1e6:.1f} GB/s", flush=True)
+
+z = ctx.eval_fd_nz(sc, x)
+torch.cuda.synchronize()
+e0.record()
+for _ in range(K):
+    ctx.eval_fd_nz(sc, x, out=z)
+e1.record(); torch.cuda.synchronize()
+ms = e0.elapsed_time(e1) / K
+print(f"H={H} N={N} structured dc/dx: {ms:.3f} ms/step, {N/ms*1e3:.3e} evals/s", flush=True)
+
+if N * mp.n * mp.m * 8 < 120e9:
+    jac = ctx.expand_jacobian(z.con_jac_nz)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(K):
+        ctx.expand_jacobian(z.con_jac_nz, out=jac)
+    e1.record(); torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / K
+    print(f"H={H} N={N} expand alone: {ms:.3f} ms/step, {N*mp.n*mp.m*8/ms/1e6:.1f} GB/s", flush=True)
