@@ -152,6 +152,23 @@ int mpc_fk(mpc_ctx *ctx, int count, const double *q, double *pose, void *stream)
 int mpc_predict_base_dynamic(mpc_ctx *ctx, int count, const double *base, const double *dyn_host,
                              double *base_traj, void *stream);
 
+/* Everything URMPC.compute_control assembles before it calls minimize (MPC:104-185), for N controllers
+ * in one launch, device to device:
+ *   active[s]    = 0 where both platform velocities are below 0.01 (the early exit, MPC:108), else 1
+ *   state0[s]    = [q, dq (zeros when dq is NULL, as mpc_action_server.py:83), ee_pose]   (MPC:148-153)
+ *   base_traj[s] = _predict_base_dynamic(base[s])                                         (MPC:606-651)
+ *   Jc[s]        = J(q[s])                                                                (MPC:157)
+ *   u_init[s]    = J^T (J J^T + 0.01 I)^-1 twist, the damped least-squares start          (MPC:112-143,168-175)
+ *   x0[s]        = previous solution shifted by one step with u_init appended where has_solution[s],
+ *                  else u_init repeated H times (MPC:177-185); x0 / prev_solution / has_solution may be NULL.
+ * q [N][6], ee_pose [N][6] = [pos, rpy], base [N][12], dyn_host as in mpc_predict_base_dynamic.
+ * The 6x6 solve is Gaussian elimination with partial pivoting in fp64; it agrees with LAPACK's to
+ * rounding, not bit for bit. */
+int mpc_prepare_tick(mpc_ctx *ctx, int count, const double *q, const double *dq, const double *ee_pose,
+                     const double *base, const double *dyn_host, const double *prev_solution,
+                     const uint8_t *has_solution, double *state0, double *base_traj, double *Jc, double *u_init,
+                     double *x0, uint8_t *active, void *stream);
+
 /* Active-set gather for lock-step solves: scipy's driver evaluates a problem only when its SLSQP core
  * asks (mode 1 / -1, _slsqp_py.py:427-456), so each round of a batched solve touches a changing subset
  * of the scenarios.  Copies rows index[i] (device int32[count], each in [0, src->count)) of every array

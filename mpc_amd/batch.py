@@ -218,6 +218,30 @@ class MpcContext:
         _ffi.check(self._ctx, self._lib.mpc_expand_jacobian(self._ctx, N, zp, jp, self._stream()))
         return jac
 
+    def prepare_tick(self, q: torch.Tensor, ee_pose: torch.Tensor, base: torch.Tensor, target: torch.Tensor,
+                     dq: Optional[torch.Tensor] = None, prev_solution: Optional[torch.Tensor] = None,
+                     has_solution: Optional[torch.Tensor] = None, u_prev: Optional[torch.Tensor] = None,
+                     has_prev: Optional[torch.Tensor] = None):
+        """What ``compute_control`` assembles before ``minimize`` (ur_mpc.py:104-185), on the device:
+        returns (ScenarioBatch, u_init [N,6], x0 [N,n], active [N] uint8)."""
+        N = int(q.shape[0])
+        qp = self._chk(q, (N, 6), "q")
+        dqp = self._chk(dq, (N, 6), "dq", optional=True)
+        ep = self._chk(ee_pose, (N, 6), "ee_pose")
+        bp = self._chk(base, (N, 12), "base")
+        self._chk(target, (N, 6), "target")
+        pp = self._chk(prev_solution, (N, self.n), "prev_solution", optional=True)
+        hp = self._chk(has_solution, (N,), "has_solution", dtype=torch.uint8, optional=True)
+        sc = ScenarioBatch(self._new(N, 18), target, self._new(N, self.H, 12), self._new(N, 36), u_prev, has_prev)
+        u_init, x0 = self._new(N, 6), self._new(N, self.n)
+        active = torch.empty(N, dtype=torch.uint8, device=self.device)
+        dyn = self.params.base_dyn_array()
+        _ffi.check(self._ctx, self._lib.mpc_prepare_tick(
+            self._ctx, N, qp, dqp, ep, bp, dyn.ctypes.data_as(C.POINTER(C.c_double)), pp, hp, sc.state0.data_ptr(),
+            sc.base_traj.data_ptr(), sc.Jc.data_ptr(), u_init.data_ptr(), x0.data_ptr(), active.data_ptr(),
+            self._stream()))
+        return sc, u_init, x0, active
+
     def gather(self, src: ScenarioBatch, index: torch.Tensor, out: ScenarioBatch) -> ScenarioBatch:
         """Rows ``index`` (int32 device tensor [k], values in [0, src.count)) of ``src`` -> the first k
         rows of ``out`` in one launch; returns that k-row view of ``out``."""

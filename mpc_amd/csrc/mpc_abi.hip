@@ -299,6 +299,31 @@ int mpc_predict_base_dynamic(mpc_ctx *ctx, int count, const double *base, const 
     return MPC_OK;
 }
 
+int mpc_prepare_tick(mpc_ctx *ctx, int count, const double *q, const double *dq, const double *ee_pose,
+                     const double *base, const double *dyn_host, const double *prev_solution,
+                     const uint8_t *has_solution, double *state0, double *base_traj, double *Jc, double *u_init,
+                     double *x0, uint8_t *active, void *stream)
+{
+    int rc = check_ready(ctx);
+    if (rc) return rc;
+    if (count < 0 || !dyn_host) return fail(ctx, MPC_ERR_INVALID_ARG, "bad count / NULL dyn");
+    for (int i = 0; i < 6; ++i)
+        if (!std::isfinite(dyn_host[i]) || (i != 2 && i != 3 && !(dyn_host[i] > 0.0)))
+            return fail(ctx, MPC_ERR_INVALID_ARG, "base dynamics: mass, I_z and the lags must be positive");
+    if (count == 0) return MPC_OK;
+    if (!q || !ee_pose || !base || !state0 || !base_traj || !Jc || !u_init || !active)
+        return fail(ctx, MPC_ERR_INVALID_ARG, "q/ee_pose/base/state0/base_traj/Jc/u_init/active must be non-NULL");
+    if ((prev_solution != nullptr) != (has_solution != nullptr))
+        return fail(ctx, MPC_ERR_INVALID_ARG, "prev_solution and has_solution go together");
+    double dyn[6];
+    std::memcpy(dyn, dyn_host, sizeof(dyn));
+    MPC_HIP(ctx, hipSetDevice(ctx->device));
+    MPC_HIP(ctx, mpck::launch_prepare_tick(ctx->params, count, dyn, q, dq, ee_pose, base, prev_solution, has_solution,
+                                           state0, base_traj, Jc, u_init, x0, active,
+                                           static_cast<hipStream_t>(stream)));
+    return MPC_OK;
+}
+
 int mpc_gather_scenarios(mpc_ctx *ctx, const mpc_scenarios *src, const int32_t *index, int count,
                          const mpc_scenarios *dst, void *stream)
 {

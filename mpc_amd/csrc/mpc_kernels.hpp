@@ -46,6 +46,12 @@ hipError_t launch_fk(const mpc_params &P, int N, const double *q, double *pose, 
 hipError_t launch_predict_base_dynamic(int N, int H, double dt, const double *base, const double (&dyn)[6],
                                        double *out, hipStream_t stream);
 
+// MPC:104-185 for N controllers: early-exit flag, state0, platform prediction, Jc, DLS start, start point
+hipError_t launch_prepare_tick(const mpc_params &P, int N, const double (&dyn)[6], const double *q, const double *dq,
+                               const double *ee_pose, const double *base, const double *prev_solution,
+                               const uint8_t *has_solution, double *state0, double *base_traj, double *Jc,
+                               double *u_init, double *x0, uint8_t *active, hipStream_t stream);
+
 // dst row i = src row index[i] for every scenario array (NaN rows for an index outside [0, src.count))
 hipError_t launch_gather_scenarios(int H, const mpc_scenarios &src, const int32_t *index, int count,
                                    const mpc_scenarios &dst, hipStream_t stream);

@@ -181,10 +181,16 @@ class BatchedMPC:
     """N controllers ticking together: the batched equivalent of ``URMPC.compute_control``
     (ur_mpc.py:83-247) including the early exit, the DLS start, warm start, output EMA and clip."""
 
-    def __init__(self, ctx: MpcContext, solver=None):
+    def __init__(self, ctx: MpcContext, solver=None, prep: str = "host"):
         """`solver`: anything with ``solve(ScenarioBatch, x0) -> BatchSolveResult`` on this context
-        (default: the in-process BatchedSLSQP; pass a ``mpc_amd.pool.SolverPool`` to use more cores)."""
+        (default: the in-process BatchedSLSQP; pass a ``mpc_amd.pool.SolverPool`` to use more cores).
+        `prep`: where the per-tick inputs are assembled.  "host" solves the 6x6 DLS system with LAPACK
+        as the reference does (start points bit-compatible with it); "device" does everything in one
+        launch of ``mpc_prepare_tick`` (start points equal to rounding; for very large batches)."""
+        if prep not in ("host", "device"):
+            raise ValueError("prep must be 'host' or 'device'")
         self.ctx = ctx
+        self.prep = prep
         self.solver = solver if solver is not None else BatchedSLSQP(ctx)
         self.previous_solution: Optional[np.ndarray] = None   # [N, n], NaN rows = no solution yet
         self.previous_control: Optional[np.ndarray] = None    # [N, 6], NaN rows = attribute absent
@@ -206,23 +212,30 @@ class BatchedMPC:
             return out
         dev = ctx.device
         up = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float64).to(dev)
-        Jc = ctx.jacobian(up(q[idx])).cpu().numpy().reshape(-1, 36)
-        bt = ctx.predict_base_dynamic(up(base[idx]))
         if not p.use_dynamic_model:
             raise NotImplementedError("the batched tick uses the dynamic platform model (controller_params.yaml:30)")
-        u_init = dls_guess(Jc, base[idx], ee_pose[idx, :3])
         prev_sol = self.previous_solution[idx]
         have_sol = ~np.isnan(prev_sol[:, 0])
-        x0 = np.tile(u_init, (1, H))
-        if have_sol.any():                                             # ur_mpc.py:178-181
-            rolled = np.roll(prev_sol[have_sol], -6, axis=1)
-            rolled[:, -6:] = u_init[have_sol]
-            x0[have_sol] = rolled
         prev_u = self.previous_control[idx]
         have_u = ~np.isnan(prev_u[:, 0])
-        state0 = np.concatenate([q[idx], np.zeros((len(idx), 6)), ee_pose[idx]], axis=1)
-        sc = ScenarioBatch(up(state0), up(target[idx]), bt, up(Jc), up(np.nan_to_num(prev_u)),
-                           torch.as_tensor(have_u.astype(np.uint8)).to(dev))
+        u_prev_d = up(np.nan_to_num(prev_u))
+        have_u_d = torch.as_tensor(have_u.astype(np.uint8)).to(dev)
+        if self.prep == "device":
+            sc, u_init_d, x0_d, _ = ctx.prepare_tick(
+                up(q[idx]), up(ee_pose[idx]), up(base[idx]), up(target[idx]), prev_solution=up(np.nan_to_num(prev_sol)),
+                has_solution=torch.as_tensor(have_sol.astype(np.uint8)).to(dev), u_prev=u_prev_d, has_prev=have_u_d)
+            u_init, x0 = u_init_d.cpu().numpy(), x0_d.cpu().numpy()
+        else:
+            Jc = ctx.jacobian(up(q[idx])).cpu().numpy().reshape(-1, 36)
+            bt = ctx.predict_base_dynamic(up(base[idx]))
+            u_init = dls_guess(Jc, base[idx], ee_pose[idx, :3])
+            x0 = np.tile(u_init, (1, H))
+            if have_sol.any():                                             # ur_mpc.py:178-181
+                rolled = np.roll(prev_sol[have_sol], -6, axis=1)
+                rolled[:, -6:] = u_init[have_sol]
+                x0[have_sol] = rolled
+            state0 = np.concatenate([q[idx], np.zeros((len(idx), 6)), ee_pose[idx]], axis=1)
+            sc = ScenarioBatch(up(state0), up(target[idx]), bt, up(Jc), u_prev_d, have_u_d)
         res = self.solver.solve(sc, x0)
         self.last = res
         ok = res.success

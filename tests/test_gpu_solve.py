@@ -175,3 +175,66 @@ def test_solver_pool_equals_single_process():
         with pytest.raises(ValueError):
             _, hs = host_scenarios(mp, 41, motion="linear", cfg_id=8)
             pool.solve(to_device(ctx, hs)[0], hs.x)
+
+
+def test_prepare_tick_matches_host_assembly():
+    """mpc_prepare_tick (one launch) against the pieces compute_control assembles on the host: exact for
+    state0, the platform prediction, Jc, the early-exit flag and the shape of x0; the 6x6 DLS solve
+    agrees with LAPACK's to rounding."""
+    from helpers import host_scenarios
+    from mpc_amd.batch import MpcContext
+    from mpc_amd.scenarios import dls_guess
+
+    mp = MpcParams.reference_yaml_defaults(horizon=20)
+    N = 257
+    ctx = MpcContext(mp, N, 0)
+    _, hs = host_scenarios(mp, N, motion="angular", cfg_id=12)
+    base = hs.base.copy()
+    base[::7, 6:12] = 0.0                      # these controllers take the early exit
+    base[1::7, 11] = 0.009                     # below the threshold too
+    ee = hs.state0[:, 12:18]
+    rng = np.random.default_rng(5)
+    prev = rng.uniform(-0.3, 0.3, (N, mp.n))
+    has = (np.arange(N) % 2).astype(np.uint8)
+    up = lambda a, dt=torch.float64: torch.as_tensor(np.ascontiguousarray(a), dtype=dt).to(ctx.device)
+    sc, u_init, x0, active = ctx.prepare_tick(up(hs.q0), up(ee), up(base), up(hs.target), prev_solution=up(prev),
+                                              has_solution=up(has, torch.uint8))
+    torch.cuda.synchronize()
+    want_active = ~((np.linalg.norm(base[:, 6:9], axis=1) < 0.01) & (np.linalg.norm(base[:, 9:12], axis=1) < 0.01))
+    np.testing.assert_array_equal(active.cpu().numpy().astype(bool), want_active)
+    assert not want_active[0] and not want_active[1] and want_active[2]
+    np.testing.assert_array_equal(sc.state0.cpu().numpy(), np.concatenate([hs.q0, np.zeros((N, 6)), ee], axis=1))
+    assert torch.equal(sc.base_traj, ctx.predict_base_dynamic(up(base)))
+    assert torch.equal(sc.Jc.view(N, 6, 6), ctx.jacobian(up(hs.q0)))
+    u_host = dls_guess(sc.Jc.cpu().numpy(), base, ee[:, :3])
+    u_dev = u_init.cpu().numpy()
+    np.testing.assert_allclose(u_dev, u_host, rtol=1e-9, atol=1e-13)
+    want_x0 = np.tile(u_dev, (1, mp.horizon))
+    rolled = np.roll(prev, -6, axis=1)
+    rolled[:, -6:] = u_dev
+    want_x0[has == 1] = rolled[has == 1]
+    np.testing.assert_array_equal(x0.cpu().numpy(), want_x0)
+    # no previous solution at all: x0 is the guess repeated
+    _, u2, x02, _ = ctx.prepare_tick(up(hs.q0), up(ee), up(base), up(hs.target))
+    assert torch.equal(u2, u_init) and torch.equal(x02, u_init.repeat(1, mp.horizon))
+
+
+def test_batched_ticks_with_device_preparation_match_host_preparation():
+    """Three ticks of 12 controllers: the start points made on the device lead to the same controls
+    (1e-6 rad/s) and the same exit modes as the LAPACK-made ones."""
+    from helpers import host_scenarios
+    from mpc_amd.batch import MpcContext
+    from mpc_amd.solver import BatchedMPC
+
+    mp = MpcParams.reference_yaml_defaults(horizon=3)
+    N = 12
+    ctx = MpcContext(mp, N, 0)
+    _, hs = host_scenarios(mp, N, motion="linear", cfg_id=13)
+    a, b = BatchedMPC(ctx, prep="host"), BatchedMPC(ctx, prep="device")
+    q, ee = hs.q0.copy(), hs.state0[:, 12:18].copy()
+    for tick in range(3):
+        ua = a.compute_control(q, ee, hs.target, hs.base)
+        ub = b.compute_control(q, ee, hs.target, hs.base)
+        np.testing.assert_allclose(ub, ua, rtol=0, atol=1e-6)
+        np.testing.assert_array_equal(b.last.status, a.last.status)
+        q = q + ua * mp.dt
