@@ -177,6 +177,48 @@ def _gather(sc: ScenarioBatch, idx: np.ndarray, device) -> ScenarioBatch:
     return ScenarioBatch(f(sc.state0), f(sc.target), f(sc.base_traj), f(sc.Jc), f(sc.u_prev), f(sc.has_prev))
 
 
+class BatchedKinematicPredictor:
+    """``_predict_base_kinematic`` (ur_mpc.py:527-601) for N controllers: the same elementwise
+    arithmetic as ``mpc_amd.ur_mpc.KinematicBasePredictor`` row by row, with each controller's
+    acceleration filters kept as rows (NaN = "no sample yet").  Only the controllers that predict on
+    a tick (``rows``) update their filters, as in the reference, where the early exit comes first."""
+
+    def __init__(self, count: int):
+        self.vel = np.full((count, 3), np.nan)
+        self.acc = np.full((count, 3), np.nan)
+        self.avel = np.full((count, 3), np.nan)
+        self.aacc = np.full((count, 3), np.nan)
+
+    @staticmethod
+    def _filter(cur, prev, prev_acc, alpha, clip, dt):
+        acc = np.zeros_like(cur)
+        seen = ~np.isnan(prev[:, 0])
+        have_acc = seen & ~np.isnan(prev_acc[:, 0])
+        raw = (cur - np.where(seen[:, None], prev, 0.0)) / dt
+        first = seen & ~have_acc
+        acc[first] = raw[first] * 0.5
+        acc[have_acc] = np.clip(alpha * raw[have_acc] + (1 - alpha) * prev_acc[have_acc], -clip, clip)
+        new_acc = prev_acc.copy()
+        new_acc[seen] = acc[seen]
+        return acc, new_acc
+
+    def predict(self, rows: np.ndarray, base: np.ndarray, horizon: int, dt: float) -> np.ndarray:
+        """base [k,12] of controllers `rows` -> [k,H,12]."""
+        lin, ang = base[:, 6:9], base[:, 9:12]
+        acc, self.acc[rows] = self._filter(lin, self.vel[rows], self.acc[rows], 0.5, 0.5, dt)
+        self.vel[rows] = lin
+        aacc, self.aacc[rows] = self._filter(ang, self.avel[rows], self.aacc[rows], 0.9, 0.3, dt)
+        self.avel[rows] = ang
+        out = np.empty((base.shape[0], horizon, 12))
+        for k in range(horizon):
+            d = min(1.0, max(0.3, 1.0 - 0.2 * k))
+            out[:, k, 0:3] = base[:, 0:3] + k * dt * lin + 0.5 * k * dt ** 2 * acc * d
+            out[:, k, 3:6] = base[:, 3:6] + k * dt * ang + 0.5 * k * dt ** 2 * aacc * d
+            out[:, k, 6:9] = lin + k * dt * acc * d
+            out[:, k, 9:12] = ang + k * dt * aacc * d
+        return out
+
+
 class BatchedMPC:
     """N controllers ticking together: the batched equivalent of ``URMPC.compute_control``
     (ur_mpc.py:83-247) including the early exit, the DLS start, warm start, output EMA and clip."""
@@ -195,6 +237,7 @@ class BatchedMPC:
         self.previous_solution: Optional[np.ndarray] = None   # [N, n], NaN rows = no solution yet
         self.previous_control: Optional[np.ndarray] = None    # [N, 6], NaN rows = attribute absent
         self.last: Optional[BatchSolveResult] = None
+        self._kin: Optional[BatchedKinematicPredictor] = None
 
     def compute_control(self, q: np.ndarray, ee_pose: np.ndarray, target: np.ndarray, base: np.ndarray) -> np.ndarray:
         """q [N,6], ee_pose [N,6] = [pos, rpy], target [N,6], base [N,12] -> controls [N,6]."""
@@ -212,8 +255,11 @@ class BatchedMPC:
             return out
         dev = ctx.device
         up = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float64).to(dev)
-        if not p.use_dynamic_model:
-            raise NotImplementedError("the batched tick uses the dynamic platform model (controller_params.yaml:30)")
+        bt_kin = None
+        if not p.use_dynamic_model:                                        # ur_mpc.py:660-663
+            if self._kin is None:
+                self._kin = BatchedKinematicPredictor(N)
+            bt_kin = up(self._kin.predict(idx, base[idx], H, p.dt))
         prev_sol = self.previous_solution[idx]
         have_sol = ~np.isnan(prev_sol[:, 0])
         prev_u = self.previous_control[idx]
@@ -225,9 +271,11 @@ class BatchedMPC:
                 up(q[idx]), up(ee_pose[idx]), up(base[idx]), up(target[idx]), prev_solution=up(np.nan_to_num(prev_sol)),
                 has_solution=torch.as_tensor(have_sol.astype(np.uint8)).to(dev), u_prev=u_prev_d, has_prev=have_u_d)
             u_init, x0 = u_init_d.cpu().numpy(), x0_d.cpu().numpy()
+            if bt_kin is not None:
+                sc.base_traj = bt_kin
         else:
             Jc = ctx.jacobian(up(q[idx])).cpu().numpy().reshape(-1, 36)
-            bt = ctx.predict_base_dynamic(up(base[idx]))
+            bt = bt_kin if bt_kin is not None else ctx.predict_base_dynamic(up(base[idx]))
             u_init = dls_guess(Jc, base[idx], ee_pose[idx, :3])
             x0 = np.tile(u_init, (1, H))
             if have_sol.any():                                             # ur_mpc.py:178-181

@@ -238,3 +238,34 @@ def test_batched_ticks_with_device_preparation_match_host_preparation():
         np.testing.assert_allclose(ub, ua, rtol=0, atol=1e-6)
         np.testing.assert_array_equal(b.last.status, a.last.status)
         q = q + ua * mp.dt
+
+
+def test_batched_mpc_with_kinematic_predictor_equals_drop_in_controllers():
+    """use_dynamic_model = False (the reference's code default, ur_mpc.py:63): the batched tick with the
+    batched kinematic predictor against one drop-in GpuURMPC per controller, three ticks with a moving
+    platform (the predictor's filters carry state from tick to tick)."""
+    import dataclasses
+
+    from helpers import host_scenarios
+    from mpc_amd.batch import MpcContext
+    from mpc_amd.solver import BatchedMPC
+
+    mp = dataclasses.replace(MpcParams.reference_yaml_defaults(horizon=3), use_dynamic_model=False)
+    N = 6
+    _, hs = host_scenarios(mp, N, motion="linear", cfg_id=14)
+    ctx = MpcContext(mp, N, 0)
+    bm = BatchedMPC(ctx)
+    singles = [GpuURMPC(mp) for _ in range(N)]
+    ee = hs.state0[:, 12:18]
+    for tick in range(3):
+        base = hs.base.copy()
+        base[:, 6] *= 1.0 + 0.1 * tick            # the platform speeds up: non-zero filtered acceleration
+        base[:, 0] += 0.01 * tick
+        u = bm.compute_control(hs.q0, ee, hs.target, base)
+        for i in range(N):
+            ui = singles[i].compute_control(
+                {"position": hs.q0[i], "velocity": np.zeros(6)}, {"position": ee[i, :3], "orientation": ee[i, 3:]},
+                {"position": hs.target[i, :3], "orientation": hs.target[i, 3:]},
+                {"position": base[i, 0:3], "orientation": base[i, 3:6], "linear_velocity": base[i, 6:9],
+                 "angular_velocity": base[i, 9:12]})
+            np.testing.assert_allclose(u[i], ui, rtol=0, atol=1e-9)

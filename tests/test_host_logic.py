@@ -55,3 +55,27 @@ def test_scenarios_are_shard_stable_and_in_bounds():
     # platform family of the reference's simulator: 0.1 Hz, amplitude 0.05-0.30 m on x
     w = 2 * np.pi * 0.1
     assert np.all(np.abs(full.base[:, 6]) <= 0.30 * w + 1e-12) and np.all(full.base[:, [1, 2, 7, 8]] == 0)
+
+
+def test_batched_kinematic_predictor_equals_per_controller_predictor():
+    """Rows of the batched predictor == one KinematicBasePredictor per controller, bit for bit, over ticks on
+    which only some controllers predict (the others took the early exit and keep their filter state)."""
+    from mpc_amd.solver import BatchedKinematicPredictor
+    from mpc_amd.ur_mpc import KinematicBasePredictor
+
+    rng = np.random.default_rng(3)
+    N, H, dt = 9, 5, 0.07
+    batched = BatchedKinematicPredictor(N)
+    single = [KinematicBasePredictor() for _ in range(N)]
+    for tick in range(6):
+        base = rng.normal(0, 0.4, (N, 12))
+        rows = np.nonzero(rng.random(N) < 0.7)[0] if tick else np.arange(0, N, 2)
+        got = batched.predict(rows, base[rows], H, dt)
+        for j, r in enumerate(rows):
+            b = base[r]
+            want = single[r].predict({"position": b[0:3], "orientation": b[3:6], "linear_velocity": b[6:9],
+                                      "angular_velocity": b[9:12]}, H, dt)
+            for k in range(H):
+                row = np.concatenate([want[k]["position"], want[k]["orientation"], want[k]["linear_velocity"],
+                                      want[k]["angular_velocity"]])
+                np.testing.assert_array_equal(got[j, k], row)
