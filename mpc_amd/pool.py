@@ -151,7 +151,8 @@ class SolverPool:
             off += k
         return K
 
-    def solve(self, sc: ScenarioBatch, x0: np.ndarray) -> BatchSolveResult:
+    def solve(self, sc: ScenarioBatch, x0: np.ndarray, progress=None, progress_every: float = 30.0) -> BatchSolveResult:
+        """`progress(seconds, n_eval, n_eval_fd, workers_done)` is called about every `progress_every` seconds."""
         ctx, v = self.ctx, self._v
         p = ctx.params
         N, n = sc.count, p.n
@@ -186,8 +187,12 @@ class SolverPool:
         fun, nit, status = np.zeros(N), np.zeros(N, int), np.zeros(N, int)
         t_core = 0.0
         rounds = 0
+        t_start = t_last = time.perf_counter()
         while busy:
             ready = connection.wait(list(busy))
+            if progress is not None and time.perf_counter() - t_last >= progress_every:
+                t_last = time.perf_counter()
+                progress(t_last - t_start, n_eval, n_eval_fd, self.workers - len(busy))
             t0 = time.perf_counter()
             req_f, req_g, answered = [], [], []
             for c in ready:
