@@ -108,7 +108,15 @@ def cpu_baseline(mp: MpcParams, hs, budget_s: float = 12.0):
                         {"position": ha.base[0, 0:3], "orientation": ha.base[0, 3:6], "linear_velocity": ha.base[0, 6:9],
                          "angular_velocity": ha.base[0, 9:12]}, info=info)
     t_solve = time.perf_counter() - t2
+    from mpc_amd.pool import host_core_budget
+    from oracle.cpu_bench import all_cores_evals_per_s
+
+    cores = host_core_budget()
+    rows = {k: v for k, v in hs.as_oracle_dict(0, min(hs.count, 4 * cores)).items() if v is not None and k != "has_prev"}
+    box_rate, box_wall = all_cores_evals_per_s(rp, rows, cores, budget=8.0)
     return {
+        "box_value": box_rate, "box_cores": cores, "box_sample": f"the same numpy path in {cores} processes at once, "
+        f"{box_wall:.1f} s",
         "solves_value": 1.0 / t_solve, "solves_unit": "solves/s", "solves_sample": f"1 angular-motion scenario, "
         f"scipy minimize(SLSQP) over the numpy callables, {info.get('nit')} iterations, {info.get('nfev')} cost calls, "
         f"{t_solve:.1f} s, single thread",
