@@ -193,6 +193,38 @@ __device__ __forceinline__ double unit_cost(const mpc_params &P, bool stage, con
 
 // num / dx from a reciprocal computed once per perturbation, with one residual correction step:
 // equal to the correctly rounded quotient except for rare last-place ties.
+// sin and cos of a joint or yaw angle.  The library routine spends ~100 VALU instructions per call on
+// double-double arithmetic and a large-argument path; angles here are a few radians (|q| <= 2 pi by
+// the joint limits), so two-constant Cody-Waite reduction by pi/2 with fma and the classic minimax
+// polynomials on [-pi/4, pi/4] (Sun fdlibm's kernel coefficients) give results within an ulp or so of
+// the correctly rounded value in about a third of the instructions.  Beyond ~1e5 rad the reduction
+// loses accuracy gradually (no large-argument path: that code would cost the kernel a wave of
+// occupancy in registers); inf and NaN give NaN like the library.
+__device__ __forceinline__ void sincos_small(double x, double *sn, double *cs)
+{
+    const double k = rint(x * 0.63661977236758134308);            // 2/pi
+    double r = fma(-k, 1.57079632679489655800e+00, x);              // pi/2, high part
+    r = fma(-k, 6.12323399573676603587e-17, r);                     // pi/2, low part
+    const double z = r * r;
+    double ps = fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
+    ps = fma(z, ps, 2.75573137070700676789e-06);
+    ps = fma(z, ps, -1.98412698298579493134e-04);
+    ps = fma(z, ps, 8.33333333332248946124e-03);
+    ps = fma(z, ps, -1.66666666666666324348e-01);
+    const double s = fma(r * z, ps, r);
+    double pc = fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
+    pc = fma(z, pc, -2.75573143513906633035e-07);
+    pc = fma(z, pc, 2.48015872894767294178e-05);
+    pc = fma(z, pc, -1.38888888888741095749e-03);
+    pc = fma(z, pc, 4.16666666666666019037e-02);
+    const double hz = 0.5 * z, a = 1.0 - hz;
+    const double c = a + (((1.0 - a) - hz) + (z * z) * pc);
+    const int q = (int)k & 3;
+    const double s1 = (q & 1) ? c : s, c1 = (q & 1) ? s : c;
+    *sn = (q & 2) ? -s1 : s1;
+    *cs = ((q + 1) & 2) ? -c1 : c1;
+}
+
 __device__ __forceinline__ double quot(double num, double dx, double rdx)
 {
     const double q = num * rdx;
@@ -241,7 +273,7 @@ __global__ __launch_bounds__(MAXT) void prefix_kernel(const mpc_params P, const 
         const int ls = f / H, k = f - ls * H;
         double *S = scen + ls * Y.total;
         double sy, cy;
-        sincos(S[Y.bt + 12 * k + 5], &sy, &cy);
+        sincos_small(S[Y.bt + 12 * k + 5], &sy, &cy);
         S[Y.ys + 2 * k] = cy;
         S[Y.ys + 2 * k + 1] = sy;
     }
@@ -269,7 +301,7 @@ __global__ __launch_bounds__(MAXT) void prefix_kernel(const mpc_params P, const 
         double sn[6], cs[6];
 #pragma unroll
         for (int j = 0; j < 6; ++j) {
-            sincos(qc[j], &sn[j], &cs[j]);
+            sincos_small(qc[j], &sn[j], &cs[j]);
             S1[Y.qs + 6 * k + j] = qc[j];
             if (!SAME_DT) S1[Y.qn + 6 * k + j] = qn[j];
             S1[Y.scs + 12 * k + j] = sn[j];
@@ -380,7 +412,7 @@ __global__ __launch_bounds__(MAXT) void prefix_kernel(const mpc_params P, const 
         const int ku = (k < H) ? k : H - 1;
         double u[6], sn[6], cs[6];
         double sa, ca;
-        sincos(qc, &sa, &ca);
+        sincos_small(qc, &sa, &ca);
 #pragma unroll
         for (int c = 0; c < 6; ++c) {
             const double ub = S2[Y.xs + 6 * ku + c];
