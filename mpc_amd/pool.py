@@ -156,6 +156,8 @@ class SolverPool:
         ctx, v = self.ctx, self._v
         p = ctx.params
         N, n = sc.count, p.n
+        if not self._procs:
+            raise RuntimeError("the solver pool is closed")
         if N > self.cap:
             raise ValueError(f"{N} scenarios > pool capacity {self.cap}")
         if N == 0:
@@ -196,7 +198,11 @@ class SolverPool:
             t0 = time.perf_counter()
             req_f, req_g, answered = [], [], []
             for c in ready:
-                msg = c.recv()
+                try:
+                    msg = c.recv()
+                except (EOFError, OSError) as exc:       # a worker died (killed, out of memory)
+                    self._abort(busy)
+                    raise RuntimeError("a solver worker process ended unexpectedly; the pool is closed") from exc
                 first, cnt = busy[c]
                 if msg[0] == "done":
                     fun[first:first + cnt], nit[first:first + cnt], status[first:first + cnt] = msg[1], msg[2], msg[3]
@@ -223,10 +229,12 @@ class SolverPool:
                                 n_eval_fd=n_eval_fd, t_core=t_core, t_serve=t_serve)
 
     def _abort(self, busy):
+        """Give up on the running solve: the workers hold half-advanced cores, so the pool is closed."""
+        busy.clear()
         for proc in self._procs:
             if proc.is_alive():
                 proc.terminate()
-        busy.clear()
+        self.close()
 
     def close(self):
         for c in self._conns:

@@ -269,3 +269,32 @@ def test_batched_mpc_with_kinematic_predictor_equals_drop_in_controllers():
                 {"position": base[i, 0:3], "orientation": base[i, 3:6], "linear_velocity": base[i, 6:9],
                  "angular_velocity": base[i, 9:12]})
             np.testing.assert_allclose(u[i], ui, rtol=0, atol=1e-9)
+
+
+def test_solver_pool_reports_a_dead_worker():
+    """A worker that dies mid-solve must surface as an error, not as a hang; the pool closes itself."""
+    from helpers import host_scenarios
+    from mpc_amd.batch import MpcContext
+    from mpc_amd.pool import SolverPool
+    from mpc_amd.scenarios import to_device
+
+    mp = MpcParams.reference_yaml_defaults(horizon=20)
+    ctx = MpcContext(mp, 32, 0)
+    _, hs = host_scenarios(mp, 32, motion="angular", cfg_id=15)
+    sc, _ = to_device(ctx, hs)
+    pool = SolverPool(ctx, workers=2, capacity=32)
+    try:
+        victim = pool._procs[1]
+        killed = []
+
+        def kill_once(t, nf, ng, done):
+            if not killed:
+                victim.kill()
+                killed.append(True)
+
+        with pytest.raises(RuntimeError, match="worker"):
+            pool.solve(sc, hs.x, progress=kill_once, progress_every=0.0)
+        with pytest.raises(RuntimeError, match="closed"):
+            pool.solve(sc, hs.x)
+    finally:
+        pool.close()
