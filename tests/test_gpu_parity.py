@@ -301,3 +301,49 @@ def test_structured_jacobian_equals_dense(H, N):
     assert not want.reshape(N, -1)[:, mask].any()
     only = ctx.eval_fd_nz(sc, x, want_grad=False, want_con=False)
     assert torch.equal(only.con_jac_nz, z.con_jac_nz) and torch.equal(only.cost, dense.cost)
+
+
+@pytest.mark.parametrize("algo", ALGOS)
+@pytest.mark.parametrize("H", [3, 10, 20, 60])
+def test_different_cost_and_constraint_time_steps(algo, H):
+    """The reference's code defaults: UR20Dynamics.dt = 0.05 drives the cost rollout, URMPC.dt = 0.1 the
+    constraint rollout (ur20_dynamics.py:19,97-98 / ur_mpc.py:30,705), other weights too.  The kernels keep
+    two joint trajectories in that case (template SAME_DT = false)."""
+    import dataclasses
+
+    from mpc_amd.params import MpcParams
+
+    mp = dataclasses.replace(MpcParams(), horizon=H, algo=algo, use_dynamic_model=True)
+    assert mp.dt != mp.dyn_dt
+    if not _supported(mp):
+        pytest.skip("algo not available for these parameters")
+    N = 48
+    co, hs = host_scenarios(mp, N, motion="angular", cfg_id=21, with_prev=True, near_bounds=True)
+    cost, grad, con, jac = co.eval_fd(hs.as_oracle_dict())
+    ctx = _ctx(mp, N)
+    sc, x = to_device(ctx, hs)
+    res = ctx.eval_fd(sc, x)
+    torch.cuda.synchronize()
+    _compare(res, cost, grad, con, jac)
+    assert torch.equal(ctx.eval(sc, x).cost, res.cost)
+    if ctx.nz_supported():
+        z = ctx.eval_fd_nz(sc, x)
+        assert torch.equal(ctx.expand_jacobian(z.con_jac_nz), res.con_jac) and torch.equal(z.grad, res.grad)
+
+
+@pytest.mark.parametrize("H", [40, 41, 42, 43, 170, 171, 255])
+def test_horizon_boundaries_of_the_kernel_variants(H):
+    """MPC_ALGO_AUTO across the hand-overs: fused kernel (LDS image, H <= ~40), long-horizon two-kernel route
+    (up to H = 170), plain rollout kernel beyond (up to MPC_MAX_HORIZON = 255)."""
+    mp = params_for(H)
+    N = 6
+    co, hs = host_scenarios(mp, N, motion="linear", cfg_id=22, near_bounds=True)
+    cost, grad, con, jac = co.eval_fd(hs.as_oracle_dict())
+    ctx = _ctx(mp, N)
+    sc, x = to_device(ctx, hs)
+    res = ctx.eval_fd(sc, x)
+    torch.cuda.synchronize()
+    _compare(res, cost, grad, con, jac)
+    assert ctx.nz_supported() == (H <= 170)
+    with pytest.raises(ValueError):
+        params_for(256)

@@ -136,3 +136,41 @@ def test_c_oracle_vs_numpy_random():
         np.testing.assert_array_equal(con[i], c)
         assert_grad_close(grad[i], g)
         np.testing.assert_array_equal(jac[i].T, a)
+
+
+def test_restatements_match_live_reference_with_code_defaults():
+    """No YAML at all: the reference's CODE defaults, where URMPC.dt (0.1, ur_mpc.py:30) and UR20Dynamics.dt
+    (0.05, ur20_dynamics.py:19) differ, so the cost rollout and the constraint rollout use different steps,
+    and the kinematic platform predictor is selected (ur_mpc.py:63).  numpy restatement == reference bit for
+    bit; the C port agrees to the usual tolerances."""
+    if not ref_shim.reference_available():
+        pytest.skip("reference tree not present")
+    from mpc_amd.params import MpcParams
+
+    mp = MpcParams()                                   # dataclass defaults = the code defaults
+    assert (mp.horizon, mp.dt, mp.dyn_dt, mp.use_dynamic_model) == (10, 0.1, 0.05, False)
+    rp = ref_params_from(mp)
+    co, hs = host_scenarios(mp, 3, motion="angular", cfg_id=32, with_prev=True)
+    c_cost, c_grad, c_con, c_jac = co.eval_fd(hs.as_oracle_dict())
+    for i in range(3):
+        ref = ref_shim.load_reference(use_yaml=False)
+        mine = NumpyRefMPC(rp)
+        ref._J_cached = hs.Jc[i].reshape(6, 6).copy()
+        mine.J_cached = hs.Jc[i].reshape(6, 6).copy()
+        ref.previous_control = hs.u_prev[i].copy()
+        mine.previous_control = hs.u_prev[i].copy()
+        tgt = {"position": hs.target[i, :3], "orientation": hs.target[i, 3:]}
+        bt = base_traj_from_array(hs.base_traj[i])
+        f_ref = ref._cost_function(hs.x[i], hs.state0[i], tgt, bt)
+        con_ref = ref._get_constraints(hs.state0[i], bt)[0]["fun"](hs.x[i])
+        assert f_ref == mine.cost_function(hs.x[i], hs.state0[i], tgt, bt)
+        np.testing.assert_array_equal(con_ref, mine.constraint(hs.x[i], hs.state0[i]))
+        assert_cost_close(c_cost[i:i + 1], np.array([f_ref]))
+        np.testing.assert_allclose(c_con[i], con_ref, rtol=1e-13, atol=1e-13)
+        b = hs.base[i]
+        bs = {"position": b[0:3], "orientation": b[3:6], "linear_velocity": b[6:9], "angular_velocity": b[9:12]}
+        for _ in range(2):                             # second call exercises the acceleration filters
+            want = base_traj_to_array(ref.predict_base_motion(bs, mp.horizon))
+            got = base_traj_to_array(mine.predict_base_motion(bs, mp.horizon))
+            np.testing.assert_array_equal(got, want)
+            bs = dict(bs, linear_velocity=bs["linear_velocity"] * 1.1, angular_velocity=bs["angular_velocity"] * 0.9)
