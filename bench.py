@@ -143,6 +143,47 @@ def measured_traffic(H, S, algo):
     return None, None
 
 
+def single_tick_latency(device, with_cpu):
+    """BASELINE.json configs[0]: ONE controller, default controller_params.yaml (H=1, linear platform motion),
+    one `compute_control` call through the drop-in class; the reference-shaped numpy path beside it."""
+    from mpc_amd.ur_mpc import GpuURMPC
+
+    mp1 = MpcParams.reference_yaml_defaults()
+    mpc = GpuURMPC(mp1, device=device)
+    ctx1 = mpc._ctx
+    hs1 = make_scenarios(mp1, DeviceKinematics(ctx1), 8, motion="linear", cfg_id=1)
+    rows = [i for i in range(8) if hs1.active[i]]
+
+    def dicts(i):
+        return ({"position": hs1.q0[i], "velocity": np.zeros(6)},
+                {"position": hs1.state0[i, 12:15], "orientation": hs1.state0[i, 15:18]},
+                {"position": hs1.target[i, :3], "orientation": hs1.target[i, 3:]},
+                {"position": hs1.base[i, 0:3], "orientation": hs1.base[i, 3:6], "linear_velocity": hs1.base[i, 6:9],
+                 "angular_velocity": hs1.base[i, 9:12]})
+
+    mpc.compute_control(*dicts(rows[0]))                  # warm (first launch, scipy import paths)
+    times = []
+    for i in rows:
+        one = GpuURMPC(mp1, device=device)
+        t0 = time.perf_counter()
+        one.compute_control(*dicts(i))
+        times.append(time.perf_counter() - t0)
+    out = {"ms_per_tick": 1e3 * float(np.median(times)), "ticks": len(times), "horizon": mp1.horizon,
+           "what": "GpuURMPC.compute_control, scipy minimize(SLSQP) with device callbacks, one scenario"}
+    if with_cpu:
+        from oracle.numpy_ref import NumpyRefMPC
+        from oracle.oracle import ref_params_from
+
+        cpu = []
+        for i in rows:
+            ref = NumpyRefMPC(ref_params_from(mp1))
+            t0 = time.perf_counter()
+            ref.compute_control(*dicts(i))
+            cpu.append(time.perf_counter() - t0)
+        out["cpu_numpy_ms_per_tick"] = 1e3 * float(np.median(cpu))
+    return out
+
+
 def solve_rate(ctx, mp, per_worker, workers, rank, world, dist):
     """MPC solves/s on a bounded sample (BASELINE.json's second metric): full SLSQP solves of
     angular-motion scenarios (configs[2] shape), one tick each.  Evaluations run on the GPU; the
@@ -372,6 +413,8 @@ def main():
             line["evals_per_s_4096_scenarios"] = 4096 / (e0.elapsed_time(e1) / args.steps * 1e-3)
         if solves is not None:
             line["solves"] = solves
+        if extras and world == 1:
+            line["single_tick_default_yaml"] = single_tick_latency(local_rank, not args.no_cpu_baseline)
         if extras and not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(mp, hs)
             line["speedup_vs_cpu_core"] = value / world / line["cpu_baseline"]["value"]

@@ -18,4 +18,6 @@ cd $R
 timeout -k 10 200 python3 -u bench.py --horizon 100 --scenarios 16384 --steps 10 --no-cpu-baseline --solve-sample 0 > $out/bench_line_H100.json
 echo "bench H=100 done"
 bash tools/pmc.sh $out/pmc 20 65536 0 > $out/pmc_summary.txt
-echo "pmc done"
+echo "pmc (dense dc/dx) done"
+bash tools/pmc.sh $out/pmc_nojac 20 65536 0 nojac > $out/pmc_summary_nojac.txt
+echo "pmc (gradient only) done"
