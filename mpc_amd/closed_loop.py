@@ -28,10 +28,11 @@ class ClosedLoopResult:
 
 
 def run_closed_loop(ctx: MpcContext, q0: np.ndarray, motion: str, amplitude: np.ndarray, phase: np.ndarray,
-                    ticks: int) -> ClosedLoopResult:
+                    ticks: int, solver=None, prep: str = "host") -> ClosedLoopResult:
+    """`solver` / `prep` as in :class:`mpc_amd.solver.BatchedMPC` (e.g. a ``SolverPool`` for many controllers)."""
     p = ctx.params
     N = q0.shape[0]
-    bm = BatchedMPC(ctx)
+    bm = BatchedMPC(ctx, solver=solver, prep=prep)
     up = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float64).to(ctx.device)
     q = np.array(q0, dtype=np.float64)
     base = platform_state(motion, amplitude, phase, 0.0)

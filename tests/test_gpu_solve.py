@@ -298,3 +298,22 @@ def test_solver_pool_reports_a_dead_worker():
             pool.solve(sc, hs.x)
     finally:
         pool.close()
+
+
+def test_closed_loop_through_the_pool_equals_one_process():
+    """Six ticks of 24 controllers: worker processes + device-side bookkeeping change nothing in the trajectory."""
+    from helpers import host_scenarios
+    from mpc_amd.batch import MpcContext
+    from mpc_amd.closed_loop import run_closed_loop
+    from mpc_amd.pool import SolverPool
+
+    mp = MpcParams.reference_yaml_defaults(horizon=3)
+    N = 24
+    ctx = MpcContext(mp, N, 0)
+    _, hs = host_scenarios(mp, N, motion="angular", cfg_id=16)
+    one = run_closed_loop(ctx, hs.q0, "angular", hs.amplitude, hs.phase, ticks=6)
+    with SolverPool(ctx, workers=3, capacity=N) as pool:
+        many = run_closed_loop(ctx, hs.q0, "angular", hs.amplitude, hs.phase, ticks=6, solver=pool)
+    np.testing.assert_array_equal(many.q, one.q)
+    np.testing.assert_array_equal(many.u, one.u)
+    np.testing.assert_array_equal(many.converged, one.converged)
