@@ -1,0 +1,64 @@
+/* libmpc_slsqp.so: native host driver for MANY SLSQP solves advancing together (no Python, no GIL).
+ *
+ * The reference solves one problem per tick with scipy.optimize.minimize(method='SLSQP')
+ * (ur_mpc.py:188-200).  scipy's driver (_slsqp_py.py:216-456) is a reverse-communication loop around a
+ * compiled core that asks for "f and c" (mode 1) or "grad f and dc/dx" (mode -1) until it is done.  This
+ * library keeps the state of `capacity` such problems in C, advances every unfinished one by one core
+ * call per round on `threads` host threads (mpc_slsqp_advance), and tells the caller which problems
+ * asked for what; the caller fills those rows (from libmpc_amd's mpc_eval / mpc_eval_fd_nz) and calls
+ * again.  The core is a C restatement of the published algorithm (mpc_amd/csrc/slsqp_core.c) pinned bit
+ * for bit against scipy's (tests/test_native_slsqp.py), so iterates equal the reference's.
+ *
+ * Problem shape is the MPC's: n = 6H variables, m = 12(H+1) inequality rows, box bounds, no equalities.
+ * dc/dx is handed over in its structured form (include/mpc_amd.h, mpc_eval_fd_nz) and expanded into the
+ * core's dense a(m, n+1) on the worker thread.  Host pointers only; nothing here touches the GPU. */
+#ifndef MPC_SLSQP_H
+#define MPC_SLSQP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mpc_slsqp_batch mpc_slsqp_batch;
+
+#define MPC_SLSQP_ABI_VERSION 1
+int mpc_slsqp_abi_version(void);
+
+/* threads <= 0: as many as OpenMP would use (OMP_NUM_THREADS).  Returns 0 or a negative code. */
+int mpc_slsqp_create(int horizon, int capacity, int threads, mpc_slsqp_batch **out);
+void mpc_slsqp_destroy(mpc_slsqp_batch *b);
+
+/* Start `count` problems: x0 [count][n] is clipped to [lb, ub] (_slsqp_py.py:268), acc = ftol,
+ * maxiter as scipy's option (_slsqp_py.py:236-241,404).  Every problem then wants f, c, grad f, dc/dx
+ * at its start point (_slsqp_py.py:419-425): fill ALL rows before the first mpc_slsqp_advance. */
+int mpc_slsqp_begin(mpc_slsqp_batch *b, int count, const double *x0, const double *lb, const double *ub, double acc,
+                    int maxiter);
+
+/* Rows the caller reads (x) and fills (f, c, g, nz); all [capacity][...] and owned by the batch:
+ * x [.][n] current iterate (evaluate at clip(x, lb, ub), _slsqp_py.py:435), f [.], c [.][m],
+ * g [.][n+1] grad f in the first n entries of each row (the last belongs to the core),
+ * nz [.][6H + 3H(H+1)] structured dc/dx. */
+double *mpc_slsqp_x(mpc_slsqp_batch *b);
+double *mpc_slsqp_f(mpc_slsqp_batch *b);
+double *mpc_slsqp_c(mpc_slsqp_batch *b);
+double *mpc_slsqp_g(mpc_slsqp_batch *b);
+double *mpc_slsqp_nz(mpc_slsqp_batch *b);
+/* Per problem after a round: mode (1 / -1: running and asking; otherwise the exit mode, 0 = success)
+ * and the major-iteration count (scipy's nit). */
+const int32_t *mpc_slsqp_mode(mpc_slsqp_batch *b);
+const int32_t *mpc_slsqp_iterations(mpc_slsqp_batch *b);
+
+/* One round: every unfinished problem makes one core call.  want_f / want_g (each [capacity]) receive the
+ * ascending indices of the problems now asking for (f, c) / (grad f, dc/dx).  Returns the number of
+ * problems still running (= *n_want_f + *n_want_g), or a negative code. */
+int mpc_slsqp_advance(mpc_slsqp_batch *b, int32_t *want_f, int32_t *n_want_f, int32_t *want_g, int32_t *n_want_g);
+
+/* Seconds spent inside the core by the busiest thread / wall seconds of all rounds since mpc_slsqp_begin. */
+double mpc_slsqp_core_seconds(const mpc_slsqp_batch *b);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MPC_SLSQP_H */

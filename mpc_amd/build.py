@@ -10,6 +10,10 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(_HERE, "libmpc_amd.so")
+SLSQP_LIB_PATH = os.path.join(_HERE, "libmpc_slsqp.so")     # host-only: the native batched SLSQP driver
+_SLSQP_UNITS = ["slsqp_core.c", "slsqp_batch.c"]
+# one rounding per operation: with it the C core reproduces scipy's compiled core bit for bit
+_SLSQP_FLAGS = ["-O3", "-ffp-contract=off", "-fPIC", "-fopenmp", "-Wall", "-std=gnu11"]
 
 # translation unit -> extra flags.  "strict" units keep one rounding per operation.
 _STRICT = ["-ffp-contract=off"]
@@ -59,7 +63,23 @@ def build(force: bool = False, verbose: bool = False) -> str:
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
+    build_slsqp(force, verbose)
     return LIB_PATH
+
+
+def build_slsqp(force: bool = False, verbose: bool = False) -> str:
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        raise RuntimeError("gcc not found: libmpc_slsqp.so cannot be built")
+    srcs = [os.path.join(CSRC, u) for u in _SLSQP_UNITS]
+    deps = srcs + [os.path.join(CSRC, "slsqp_core.h"), os.path.join(_ROOT, "include", "mpc_slsqp.h")]
+    if force or _stale(SLSQP_LIB_PATH, deps):
+        cmd = [gcc] + _SLSQP_FLAGS + ["-shared", "-I" + os.path.join(_ROOT, "include"), "-I" + CSRC, "-o", SLSQP_LIB_PATH] \
+            + srcs + ["-lm"]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return SLSQP_LIB_PATH
 
 
 if __name__ == "__main__":

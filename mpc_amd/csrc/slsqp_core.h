@@ -1,0 +1,30 @@
+/* SLSQP core (host C): one reverse-communication call, see slsqp_core.c. */
+#ifndef MPC_SLSQP_CORE_H
+#define MPC_SLSQP_CORE_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* the scalars the Fortran original keeps in SAVEd variables / scipy passes back and forth (_slsqp_py.py:396-409) */
+typedef struct slsqp_state {
+    double alpha, f0, gs, h1, h2, h3, h4, t, t0, tol;
+    int iexact, incons, ireset, itermx, line, n1, n2, n3;
+} slsqp_state;
+
+/* Body of the method with its persistent vectors passed one by one: r [m + 2n + 2] multipliers,
+ * l [(n+1)n/2 + 1] LDL' factor of the BFGS matrix, x0 [n], mu [m], s / u / v [n+1], and per-call
+ * scratch w (doubles) / iw (ints).  a is column-major (la, n+1).  mode: 0 on the first call, then
+ * what the caller was asked for (1: f and c are fresh, -1: g and a are fresh). */
+void mpc_slsqpb(int m, int meq, int la, int n, double *x, double *xl, double *xu, double f, double *c, double *g,
+                double *a, double *acc, int *iter, int *mode, double *r, double *l, double *x0, double *mu, double *s,
+                double *u, double *v, double *w, int *iw, slsqp_state *S);
+
+/* Same call with scipy's single workspace array (layout of the Fortran driver SLSQP), for side-by-side tests. */
+void mpc_slsqp_step(int m, int meq, int la, int n, double *x, double *xl, double *xu, double f, double *c, double *g,
+                    double *a, double *acc, int *iter, int *mode, double *w, int l_w, int *jw, int l_jw, slsqp_state *S);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

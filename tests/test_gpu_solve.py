@@ -317,3 +317,35 @@ def test_closed_loop_through_the_pool_equals_one_process():
     np.testing.assert_array_equal(many.q, one.q)
     np.testing.assert_array_equal(many.u, one.u)
     np.testing.assert_array_equal(many.converged, one.converged)
+
+
+def test_native_driver_equals_scipy_core_driver():
+    """libmpc_slsqp.so (C core on host threads, evaluations from the GPU) against the lock-step driver over
+    scipy's compiled core: identical iterates, exit modes, iteration counts and evaluation counts."""
+    from helpers import host_scenarios
+    from mpc_amd.batch import MpcContext
+    from mpc_amd.native_solver import NativeBatchedSLSQP
+    from mpc_amd.scenarios import to_device
+    from mpc_amd.solver import BatchedMPC, BatchedSLSQP
+
+    for H, count, prev in ((3, 40, True), (20, 24, False)):
+        mp = MpcParams.reference_yaml_defaults(horizon=H)
+        ctx = MpcContext(mp, 64, 0)
+        _, hs = host_scenarios(mp, count, motion="angular", cfg_id=18, with_prev=prev)
+        sc, _ = to_device(ctx, hs)
+        one = BatchedSLSQP(ctx).solve(sc, hs.x)
+        with NativeBatchedSLSQP(ctx, threads=3) as native:
+            two = native.solve(sc, hs.x)
+            again = native.solve(sc.slice(0, 5), hs.x[:5])           # the batch object is reusable
+            np.testing.assert_array_equal(two.x, one.x)
+            np.testing.assert_array_equal(two.status, one.status)
+            np.testing.assert_array_equal(two.nit, one.nit)
+            np.testing.assert_array_equal(two.fun, one.fun)
+            assert (two.n_eval, two.n_eval_fd) == (one.n_eval, one.n_eval_fd)
+            np.testing.assert_array_equal(again.x, one.x[:5])
+            # and as the solver of the batched controller
+            a, b = BatchedMPC(ctx), BatchedMPC(ctx, solver=native)
+            for _ in range(2):
+                ua = a.compute_control(hs.q0, hs.state0[:, 12:18], hs.target, hs.base)
+                ub = b.compute_control(hs.q0, hs.state0[:, 12:18], hs.target, hs.base)
+                np.testing.assert_array_equal(ub, ua)

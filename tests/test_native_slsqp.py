@@ -1,0 +1,96 @@
+"""CPU: the native SLSQP core and batched driver (libmpc_slsqp.so) against scipy's compiled core.
+The C oracle serves the evaluations (test infrastructure; the product serves them from libmpc_amd)."""
+import numpy as np
+import pytest
+
+from helpers import host_scenarios, params_for
+from mpc_amd.native_solver import NativeBatch
+from mpc_amd.slsqp_state import Problem, nz_scatter_index
+
+
+def _row(hs, i, x):
+    d = hs.as_oracle_dict(i, i + 1)
+    d["x"] = np.asarray(x, float).reshape(1, -1)
+    return d
+
+
+def _rows(hs, idx, X):
+    d = {k: (None if v is None else v[idx]) for k, v in hs.as_oracle_dict().items()}
+    d["x"] = np.ascontiguousarray(X)
+    return d
+
+
+def _scipy_core_solve(co, hs, i, mp, lb, ub, x0):
+    """scipy's own compiled core, driven like _minimize_slsqp does; returns the per-call history."""
+    n, m = mp.n, mp.m
+    A = np.zeros((n + 1, m))
+    p = Problem(np.clip(x0, lb, ub).copy(), n, m, mp.ftol, mp.maxiter, A.T)
+    f, g, c, a = co.eval_fd(_row(hs, i, p.x))
+    p.fx, p.c[:], p.g[:n], A[:n] = float(f[0]), c[0], g[0], a[0]
+    hist = []
+    while not p.done:
+        md = p.step(lb, ub)
+        hist.append((md, p.x.copy()))
+        xc = np.clip(p.x, lb, ub)
+        if md == 1:
+            f, c = co.eval(_row(hs, i, xc))
+            p.fx, p.c[:] = float(f[0]), c[0]
+        elif md == -1:
+            _, g, _, a = co.eval_fd(_row(hs, i, xc))
+            p.g[:n], A[:n] = g[0], a[0]
+    return p, hist
+
+
+@pytest.mark.parametrize("H,N,motion,prev", [(1, 12, "linear", False), (3, 10, "angular", True), (20, 5, "angular", False)])
+def test_native_batch_reproduces_scipy_core_call_by_call(H, N, motion, prev):
+    """Every round of the native driver leaves every problem exactly where scipy's core leaves it after the
+    same number of calls: same mode, bit-identical x; same exit mode, iteration count and f at the end."""
+    mp = params_for(H)
+    co, hs = host_scenarios(mp, N, motion=motion, cfg_id=41, with_prev=prev, goal_jitter=0.0 if H == 20 else 0.05)
+    n, m = mp.n, mp.m
+    lb = np.array([b[0] for b in mp.bounds()])
+    ub = np.array([b[1] for b in mp.bounds()])
+    x0 = np.tile(hs.u_init, (1, H))
+    want = [_scipy_core_solve(co, hs, i, mp, lb, ub, x0[i]) for i in range(N)]
+    scatter = nz_scatter_index(H)
+    b = NativeBatch(H, N + 3, threads=3)
+    b.begin(x0, lb, ub, mp.ftol, mp.maxiter)
+    f, g, c, a = co.eval_fd(_rows(hs, np.arange(N), b.X[:N]))
+    b.F[:N], b.Cc[:N], b.G[:N, :n], b.NZ[:N] = f, c, g, a.reshape(N, -1)[:, scatter]
+    calls = np.zeros(N, int)
+    running = np.ones(N, bool)
+    while running.any():
+        want_f, want_g = (w.copy() for w in b.advance())
+        for i in np.nonzero(running)[0]:
+            md, x = want[i][1][calls[i]]
+            assert int(b.mode[i]) == md
+            np.testing.assert_array_equal(b.X[i], x)
+            calls[i] += 1
+            if md not in (1, -1):
+                running[i] = False
+        assert sorted(np.concatenate([want_f, want_g])) == list(np.nonzero(running)[0])
+        if len(want_f):
+            f, c = co.eval(_rows(hs, want_f, np.clip(b.X[want_f], lb, ub)))
+            b.F[want_f], b.Cc[want_f] = f, c
+        if len(want_g):
+            _, g, _, a = co.eval_fd(_rows(hs, want_g, np.clip(b.X[want_g], lb, ub)))
+            b.G[want_g, :n] = g
+            b.NZ[want_g] = a.reshape(len(want_g), -1)[:, scatter]
+    for i in range(N):
+        p = want[i][0]
+        assert int(b.mode[i]) == int(p.mode) and int(b.iterations[i]) == int(p.majiter)
+        assert b.F[i] == p.fx
+        assert calls[i] == len(want[i][1])
+    assert b.core_seconds > 0.0
+    b.close()
+
+
+def test_native_batch_argument_checks():
+    with pytest.raises(ValueError):
+        NativeBatch(0, 4)
+    b = NativeBatch(1, 2, threads=1)
+    with pytest.raises(ValueError):
+        b.begin(np.zeros((3, 6)), -np.ones(6), np.ones(6), 1e-3, 50)      # more problems than capacity
+    b.begin(np.full((2, 6), 5.0), -np.ones(6), np.ones(6), 1e-3, 50)
+    np.testing.assert_array_equal(b.X, np.ones((2, 6)))                   # start point clipped to the bounds
+    b.close()

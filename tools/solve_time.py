@@ -42,6 +42,16 @@ def main():
             reg = pool._registered
         print(f"pool W={W} M={k}: start {t1-t0:.1f}s warm {t2-t1:.2f}s solve {t3-t2:.2f}s -> {k/(t3-t2):.1f} solves/s; "
               f"core_max={r.t_core:.2f} server_busy={r.t_serve:.2f} conv={int(r.success.sum())} pinned_shm={reg}", flush=True)
+    from mpc_amd.native_solver import NativeBatchedSLSQP
+    for W in Ws:
+        k = PER_WORKER * W
+        with NativeBatchedSLSQP(ctx, threads=W, capacity=k) as native:
+            native.solve(sc_all.slice(0, W), x0[:W])   # warm
+            t2 = time.perf_counter()
+            r = native.solve(sc_all.slice(0, k), x0[:k])
+            t3 = time.perf_counter()
+        print(f"native T={W} M={k}: solve {t3-t2:.2f}s -> {k/(t3-t2):.1f} solves/s; core_max={r.t_core:.2f} serve={r.t_serve:.2f} "
+              f"rounds={r.rounds} conv={int(r.success.sum())}", flush=True)
 
 
 if __name__ == "__main__":
