@@ -184,13 +184,14 @@ def single_tick_latency(device, with_cpu):
     return out
 
 
-def solve_rate(ctx, mp, per_worker, workers, rank, world, dist):
+def solve_rate(ctx, mp, per_thread, threads, rank, world, dist):
     """MPC solves/s on a bounded sample (BASELINE.json's second metric): full SLSQP solves of
     angular-motion scenarios (configs[2] shape), one tick each.  Evaluations run on the GPU; the
-    quadratic subproblems run in scipy's compiled core in `workers` host processes per GPU
-    (mpc_amd/pool.py), so this rate is host-bound and scales with host cores, not with the GPU.
-    Every rank calls this; a rank that fails reports it and all ranks skip together (no hang)."""
-    from mpc_amd.pool import SolverPool
+    quadratic subproblems run in the native host driver (libmpc_slsqp.so: C restatement of scipy's SLSQP
+    core, bit-identical iterates) on `threads` host threads per GPU, so this rate is host-bound and
+    scales with host cores, not with the GPU.  Every rank calls this; a rank that fails reports it and
+    all ranks skip together (no hang)."""
+    from mpc_amd.native_solver import NativeBatchedSLSQP
     from mpc_amd.solver import BatchedMPC
 
     def all_ok(ok):
@@ -200,24 +201,24 @@ def solve_rate(ctx, mp, per_worker, workers, rank, world, dist):
         all_reduce(dist, t, dist.ReduceOp.MIN)       # doubles as the barrier before the timed part
         return bool(t.item() > 0.5)
 
-    count = per_worker * workers
-    pool, err, hs, bm, dt = None, None, None, None, 0.0
+    count = min(per_thread * threads, ctx.max_scenarios)
+    native, err, hs, bm, dt = None, None, None, None, 0.0
     try:
         hs = make_scenarios(mp, DeviceKinematics(ctx), count, motion="angular", cfg_id=3, goal_jitter=0.0,
                             first=rank * count)
-        pool = SolverPool(ctx, workers, capacity=count)
-        log("pool up")
-        warm = min(count, workers)
-        BatchedMPC(ctx, solver=pool).compute_control(hs.q0[:warm], hs.state0[:warm, 12:18], hs.target[:warm], hs.base[:warm])
+        native = NativeBatchedSLSQP(ctx, threads=threads, capacity=count)
+        log("native solver up")
+        warm = min(count, 2 * threads)
+        BatchedMPC(ctx, solver=native).compute_control(hs.q0[:warm], hs.state0[:warm, 12:18], hs.target[:warm], hs.base[:warm])
         torch.cuda.synchronize()
     except Exception as exc:  # noqa: BLE001 - the evals/s line must survive a host-side problem
         err = repr(exc)
     try:
-        log(f"pool warm, err={err}")
+        log(f"native solver warm, err={err}")
         if not all_ok(err is None):
-            return {"error": err or "another rank failed to start its solver pool"}
+            return {"error": err or "another rank failed to start its solver"}
         try:
-            bm = BatchedMPC(ctx, solver=pool)
+            bm = BatchedMPC(ctx, solver=native)
             t0 = time.perf_counter()
             bm.compute_control(hs.q0, hs.state0[:, 12:18], hs.target, hs.base)
             dt = time.perf_counter() - t0
@@ -226,8 +227,8 @@ def solve_rate(ctx, mp, per_worker, workers, rank, world, dist):
         if not all_ok(err is None):
             return {"error": err or "another rank failed during its solves"}
     finally:
-        if pool is not None:
-            pool.close()
+        if native is not None:
+            native.close()
     r = bm.last
     stats = torch.tensor([dt, float(hs.active.sum()), float(r.success.sum()), float(r.n_eval_fd), float(r.n_eval)],
                          dtype=torch.float64, device=ctx.device)
@@ -237,12 +238,29 @@ def solve_rate(ctx, mp, per_worker, workers, rank, world, dist):
         all_reduce(dist, stats, dist.ReduceOp.SUM)
         stats[0] = mx[0]
     dt_all, solved, conv, nfd, nf = (float(v) for v in stats.tolist())
-    return {"value": solved / dt_all, "unit": "solves/s", "host_bound": True, "host_processes_per_gpu": workers,
+    return {"value": solved / dt_all, "unit": "solves/s", "host_bound": True, "host_threads_per_gpu": threads,
             "sample": f"{int(solved)} angular-motion scenarios ({count} per GPU), H={mp.horizon}, one tick each, "
-                      f"{int(conv)} converged, {int(nfd)} eval_fd + {int(nf)} eval scenario-evals on the GPU, SLSQP cores in "
-                      f"{workers} worker processes per GPU",
+                      f"{int(conv)} converged, {int(nfd)} eval_fd + {int(nf)} eval scenario-evals on the GPU, SLSQP cores "
+                      f"(libmpc_slsqp.so) on {threads} host threads per GPU",
             "seconds": dt_all, "mean_iterations": float(r.nit.mean()), "rounds_rank0": r.rounds,
-            "rank0_max_seconds_in_slsqp_core_per_worker": r.t_core, "rank0_seconds_server_busy": r.t_serve}
+            "rank0_core_seconds_busiest_thread": r.t_core, "rank0_seconds_serving_from_gpu": r.t_serve}
+
+
+def pool_solve_rate(ctx, mp, per_worker, workers):
+    """The same sample shape through the process pool over scipy's own compiled core (mpc_amd/pool.py)."""
+    from mpc_amd.pool import SolverPool
+    from mpc_amd.solver import BatchedMPC
+
+    count = per_worker * workers
+    hs = make_scenarios(mp, DeviceKinematics(ctx), count, motion="angular", cfg_id=3, goal_jitter=0.0)
+    with SolverPool(ctx, workers, capacity=count) as pool:
+        BatchedMPC(ctx, solver=pool).compute_control(hs.q0[:workers], hs.state0[:workers, 12:18], hs.target[:workers], hs.base[:workers])
+        bm = BatchedMPC(ctx, solver=pool)
+        t0 = time.perf_counter()
+        bm.compute_control(hs.q0, hs.state0[:, 12:18], hs.target, hs.base)
+        dt = time.perf_counter() - t0
+    return {"value": float(hs.active.sum()) / dt, "unit": "solves/s", "workers": workers,
+            "sample": f"{int(hs.active.sum())} scenarios, scipy's compiled SLSQP core in {workers} worker processes"}
 
 
 def main():
@@ -255,9 +273,9 @@ def main():
     ap.add_argument("--motion", default="linear", choices=["linear", "angular"])
     ap.add_argument("--algo", type=int, default=_ffi.ALGO_AUTO)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--solve-sample", type=int, default=64,
-                    help="scenarios per worker process in the bounded solves/s sample (0: skip)")
-    ap.add_argument("--solve-workers", type=int, default=0, help="SLSQP worker processes per GPU (0: host cores - 1)")
+    ap.add_argument("--solve-sample", type=int, default=256,
+                    help="scenarios per host thread in the bounded solves/s sample (0: skip)")
+    ap.add_argument("--solve-workers", type=int, default=0, help="SLSQP host threads per GPU (0: host cores - 1)")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="development only: every rank uses device 0 and the process group is gloo, to walk the "
                          "multi-rank code path on a one-GPU box (the numbers mean nothing)")
@@ -338,7 +356,7 @@ def main():
 
         local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
         workers = args.solve_workers or max(1, min(15, host_core_budget(local_world) - 1))
-        log(f"solves leg: {workers} workers")
+        log(f"solves leg: {workers} host threads")
         solves = solve_rate(ctx, mp, args.solve_sample, workers, rank, world, dist)
         log("solves leg done")
 
@@ -413,6 +431,11 @@ def main():
             line["evals_per_s_4096_scenarios"] = 4096 / (e0.elapsed_time(e1) / args.steps * 1e-3)
         if solves is not None:
             line["solves"] = solves
+            if extras and world == 1 and "error" not in solves:
+                try:
+                    line["solves_scipy_core_pool"] = pool_solve_rate(ctx, mp, 32, solves["host_threads_per_gpu"])
+                except Exception as exc:  # noqa: BLE001 - a comparison figure, not the metric
+                    line["solves_scipy_core_pool"] = {"error": repr(exc)}
         if extras and world == 1:
             line["single_tick_default_yaml"] = single_tick_latency(local_rank, not args.no_cpu_baseline)
         if extras and not args.no_cpu_baseline and world == 1:

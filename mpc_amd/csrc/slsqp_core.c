@@ -19,7 +19,16 @@
 
 static const double epmach = 2.22e-16;
 
-static double ddot_sl(int n, const double *dx, int incx, const double *dy, int incy)
+/* The hot loops are element-wise over contiguous runs; a second copy of these functions compiled for AVX2
+ * is picked at load time where the CPU has it (no FMA contraction in either copy: -ffp-contract=off, so
+ * both produce the same bits). */
+#if defined(__x86_64__) && defined(__GNUC__) && !defined(MPC_SLSQP_NO_CLONES)
+#define HOT __attribute__((target_clones("default", "avx2")))
+#else
+#define HOT
+#endif
+
+HOT static double ddot_sl(int n, const double *dx, int incx, const double *dy, int incy)
 {
     double t = 0.0;
     if (n <= 0) return 0.0;
@@ -39,7 +48,7 @@ static double ddot_sl(int n, const double *dx, int incx, const double *dy, int i
     return t;
 }
 
-static void daxpy_sl(int n, double da, const double *dx, int incx, double *dy, int incy)
+HOT static void daxpy_sl(int n, double da, const double *dx, int incx, double *dy, int incy)
 {
     int i, ix = 0, iy = 0;
     if (n <= 0 || da == 0.0) return;
@@ -92,7 +101,7 @@ static void dsrotg(double *da, double *db, double *c, double *s)
     *db = z;
 }
 
-static void dsrot(int n, double *dx, int incx, double *dy, int incy, double c, double s)
+HOT static void dsrot(int n, double *dx, int incx, double *dy, int incy, double c, double s)
 {
     int i, ix = 0, iy = 0;
     for (i = 0; i < n; ++i) {
@@ -104,7 +113,7 @@ static void dsrot(int n, double *dx, int incx, double *dy, int incy, double c, d
 }
 
 /* Householder transformation (Lawson & Hanson H12).  u(1,j) = u[(j-1)*iue]; c addressed 1-based. */
-static void h12(int mode, int lpivot, int l1, int m, double *u, int iue, double *up, double *c, int ice, int icv, int ncv)
+HOT static void h12(int mode, int lpivot, int l1, int m, double *u, int iue, double *up, double *c, int ice, int icv, int ncv)
 {
 #define U(j) u[((j) - 1) * iue]
     double cl, clinv, sm, b;
@@ -143,7 +152,7 @@ static void h12(int mode, int lpivot, int l1, int m, double *u, int iue, double 
 }
 
 /* Non-negative least squares (Lawson & Hanson NNLS): min ||a x - b||, x >= 0.  a(mda, n) column-major. */
-static void nnls(double *a, int mda, int m, int n, double *b, double *x, double *rnorm, double *w, double *z, int *index, int *mode)
+HOT static void nnls(double *a, int mda, int m, int n, double *b, double *x, double *rnorm, double *w, double *z, int *index, int *mode)
 {
 #define A(i, j) a[((i) - 1) + ((j) - 1) * mda]
     const double factor = 1.0e-2;
@@ -259,7 +268,7 @@ L280:
 }
 
 /* Least distance programming: min ||x|| s.t. g x >= h.  g(mg, n) column-major with m rows used. */
-static void ldp(double *g, int mg, int m, int n, double *h, double *x, double *xnorm, double *w, int *index, int *mode)
+HOT static void ldp(double *g, int mg, int m, int n, double *h, double *x, double *xnorm, double *w, int *index, int *mode)
 {
 #define G(i, j) g[((i) - 1) + ((j) - 1) * mg]
     int i, j, iw, iff, iz, iy, iwdual, n1;
@@ -302,7 +311,7 @@ static void ldp(double *g, int mg, int m, int n, double *h, double *x, double *x
 }
 
 /* Inequality-constrained least squares: min ||e x - f|| s.t. g x >= h. */
-static void lsi(double *e, double *f, double *g, double *h, int le, int me, int lg, int mg, int n, double *x, double *xnorm,
+HOT static void lsi(double *e, double *f, double *g, double *h, int le, int me, int lg, int mg, int n, double *x, double *xnorm,
                 double *w, int *jw, int *mode)
 {
 #define E(i, j) e[((i) - 1) + ((j) - 1) * le]
@@ -357,6 +366,18 @@ static void lsi(double *e, double *f, double *g, double *h, int le, int me, int 
          * contiguous): per entry the same products are added in the same order as in the row-by-row text
          * of Lawson & Hanson, so every rounded value is the same; only the memory walk differs. */
         double acc[mg > 0 ? mg : 1];
+        /* Rows of g that start with exact zeros (the +-identity rows of the box bounds, the velocity rows)
+         * keep them through the transformation, and a product with an exact zero adds nothing to a sum that
+         * started at +0: blocks of rows whose first non-zero lies right of the current columns are skipped. */
+        enum { RB = 16 };
+        const int nblk = (mg + RB - 1) / RB;
+        int first[nblk > 0 ? nblk : 1];
+        for (k = 0; k < nblk; ++k) first[k] = n + 1;
+        for (j = n; j >= 1; --j) {
+            const double *gj = &G(1, j);
+            for (i = 0; i < mg; ++i)
+                if (gj[i] != 0.0) first[i / RB] = j;
+        }
         for (j = 1; j <= n; ++j) {
             const double ejj = E(j, j);
             double *gj = &G(1, j);
@@ -364,13 +385,17 @@ static void lsi(double *e, double *f, double *g, double *h, int le, int me, int 
             for (k = 1; k + 3 < j; k += 4) {     /* four terms per pass over the rows, added in the same order */
                 const double e0 = E(k, j), e1 = E(k + 1, j), e2 = E(k + 2, j), e3 = E(k + 3, j);
                 const double *g0 = &G(1, k), *g1 = &G(1, k + 1), *g2 = &G(1, k + 2), *g3 = &G(1, k + 3);
-                for (i = 0; i < mg; ++i) {
-                    double a = acc[i];
-                    a = a + g0[i] * e0;
-                    a = a + g1[i] * e1;
-                    a = a + g2[i] * e2;
-                    a = a + g3[i] * e3;
-                    acc[i] = a;
+                for (int blk = 0; blk < nblk; ++blk) {
+                    if (first[blk] > k + 3) continue;
+                    const int hi = MIN(mg, (blk + 1) * RB);
+                    for (i = blk * RB; i < hi; ++i) {
+                        double a = acc[i];
+                        a = a + g0[i] * e0;
+                        a = a + g1[i] * e1;
+                        a = a + g2[i] * e2;
+                        a = a + g3[i] * e3;
+                        acc[i] = a;
+                    }
                 }
             }
             for (; k < j; ++k) {
@@ -433,7 +458,7 @@ static void lsei_noeq(double *e, double *f, double *g, double *h, int le, int me
 }
 
 /* QP subproblem in least-squares form (Kraft): e = sqrt(d) l^T, f = -d^(-1/2) l^(-1) g. */
-static void lsq(int m, int meq, int n, int nl, int la, double *l, double *g, double *a, double *b, double *xl, double *xu,
+HOT static void lsq(int m, int meq, int n, int nl, int la, double *l, double *g, double *a, double *b, double *xl, double *xu,
                 double *x, double *y, double *w, int *jw, int *mode)
 {
     int i, j, i1, i2, i3, i4, ie, iff, ic, id, ig, ih, il, ip, iw, m1, mineq, n1, n2, n3, nancnt;

@@ -122,13 +122,21 @@ class NativeBatch:
 
 
 class NativeBatchedSLSQP:
-    def __init__(self, ctx: MpcContext, threads: int = 0, capacity: int = None):
+    """`groups` = 2 splits a batch into two halves that alternate: while the host threads advance one
+    half inside the C library (the GIL is released), this thread serves the other half's evaluations
+    from the GPU, so device calls and copies hide behind the cores."""
+
+    def __init__(self, ctx: MpcContext, threads: int = 0, capacity: int = None, groups: int = 2):
         if not ctx.nz_supported():
             raise ValueError("the native driver takes dc/dx in its structured form: the context needs MPC_ALGO_PREFIX")
+        if groups not in (1, 2):
+            raise ValueError("groups must be 1 or 2")
         self.ctx = ctx
         p = ctx.params
         self.cap = int(capacity or ctx.max_scenarios)
-        self.batch = NativeBatch(p.horizon, self.cap, threads)
+        self.groups = groups
+        self._gcap = (self.cap + groups - 1) // groups
+        self.batches = [NativeBatch(p.horizon, self._gcap, threads) for _ in range(groups)]
         self.lb = np.array([b[0] for b in p.bounds()])
         self.ub = np.array([b[1] for b in p.bounds()])
         dev, n, m = ctx.device, p.n, p.m
@@ -137,64 +145,108 @@ class NativeBatchedSLSQP:
         self._out = EvalResult(z(self.cap), z(self.cap, n), z(self.cap, m), None, z(self.cap, ctx.nz_count))
         self._sub = {False: ScenarioBatch.empty(dev, self.cap, p.horizon, False),
                      True: ScenarioBatch.empty(dev, self.cap, p.horizon, True)}
+        from concurrent.futures import ThreadPoolExecutor
 
-    def _serve(self, sc: ScenarioBatch, idx: np.ndarray, need_grad: bool):
-        ctx, b, o = self.ctx, self.batch, self._out
-        K, N = len(idx), sc.count
-        full = K == N
-        rows = slice(0, N) if full else idx
-        self._x_dev[:K].copy_(torch.from_numpy(np.clip(b.X[rows], self.lb, self.ub)))       # _clip_x_for_func
-        sub = sc if full else ctx.gather(sc, torch.from_numpy(idx).to(ctx.device), self._sub[sc.u_prev is not None])
+        self._helper = ThreadPoolExecutor(max_workers=1)
+
+    def _serve(self, sc: ScenarioBatch, b: NativeBatch, first: int, idx: np.ndarray, need_grad: bool):
+        """Evaluate rows `idx` of group `b` (scenarios first + idx of the batch) in one launch."""
+        ctx, o = self.ctx, self._out
+        K = len(idx)
+        self._x_dev[:K].copy_(torch.from_numpy(np.clip(b.X[idx], self.lb, self.ub)))       # _clip_x_for_func
+        gidx = torch.from_numpy((idx + first).astype(np.int32)).to(ctx.device)
+        sub = ctx.gather(sc, gidx, self._sub[sc.u_prev is not None])
         if need_grad:
             ctx.eval_fd_nz(sub, self._x_dev[:K], want_con=False,
                            out=EvalResult(o.cost[:K], o.grad[:K], None, None, o.con_jac_nz[:K]))
-            b.G[rows, :b.n] = o.grad[:K].cpu().numpy()
-            b.NZ[rows] = o.con_jac_nz[:K].cpu().numpy()
+            b.G[idx, :b.n] = o.grad[:K].cpu().numpy()
+            b.NZ[idx] = o.con_jac_nz[:K].cpu().numpy()
         else:
             ctx.eval(sub, self._x_dev[:K], out=EvalResult(o.cost[:K], None, o.con[:K], None))
-            b.F[rows] = o.cost[:K].cpu().numpy()
-            b.Cc[rows] = o.con[:K].cpu().numpy()
+            b.F[idx] = o.cost[:K].cpu().numpy()
+            b.Cc[idx] = o.con[:K].cpu().numpy()
 
     def solve(self, sc: ScenarioBatch, x0: np.ndarray) -> BatchSolveResult:
-        ctx, b = self.ctx, self.batch
+        ctx = self.ctx
         p = ctx.params
         N, n = sc.count, p.n
         if N > self.cap:
             raise ValueError(f"{N} scenarios > capacity {self.cap}")
         if N == 0:
             return BatchSolveResult(np.zeros((0, n)), np.zeros(0), np.zeros(0, int), np.zeros(0, int), 0, 0, 0)
-        b.begin(np.asarray(x0, dtype=np.float64).reshape(N, n), self.lb, self.ub, p.ftol, p.maxiter)
+        x0 = np.asarray(x0, dtype=np.float64).reshape(N, n)
+        G = self.groups if N >= 2 * self.groups else 1
+        per = (N + G - 1) // G
+        spans = [(g * per, min(N, (g + 1) * per) - g * per) for g in range(G)]
+        bs = self.batches[:G]
+        for b, (first, cnt) in zip(bs, spans):
+            b.begin(x0[first:first + cnt], self.lb, self.ub, p.ftol, p.maxiter)
         t_serve = 0.0
         t0 = time.perf_counter()
         # mode 0 on entry: f, c, grad f, dc/dx at the start point for everyone (_slsqp_py.py:419-425)
         o = self._out
-        self._x_dev[:N].copy_(torch.from_numpy(b.X[:N]))
+        for b, (first, cnt) in zip(bs, spans):
+            self._x_dev[first:first + cnt].copy_(torch.from_numpy(b.X[:cnt]))
         ctx.eval_fd_nz(sc, self._x_dev[:N], out=EvalResult(o.cost[:N], o.grad[:N], o.con[:N], None, o.con_jac_nz[:N]))
-        b.F[:N] = o.cost[:N].cpu().numpy()
-        b.Cc[:N] = o.con[:N].cpu().numpy()
-        b.G[:N, :n] = o.grad[:N].cpu().numpy()
-        b.NZ[:N] = o.con_jac_nz[:N].cpu().numpy()
+        cost, con, grad, nz = (t[:N].cpu().numpy() for t in (o.cost, o.con, o.grad, o.con_jac_nz))
+        for b, (first, cnt) in zip(bs, spans):
+            b.F[:cnt], b.Cc[:cnt], b.G[:cnt, :n], b.NZ[:cnt] = (a[first:first + cnt] for a in (cost, con, grad, nz))
         t_serve += time.perf_counter() - t0
         n_eval, n_eval_fd, rounds = 0, N, 0
-        while True:
-            want_f, want_g = b.advance()
-            rounds += 1
-            if len(want_f) == 0 and len(want_g) == 0:
-                break
-            t0 = time.perf_counter()
-            if len(want_f):
-                self._serve(sc, want_f.copy(), False)
-                n_eval += len(want_f)
-            if len(want_g):
-                self._serve(sc, want_g.copy(), True)
-                n_eval_fd += len(want_g)
-            t_serve += time.perf_counter() - t0
-        return BatchSolveResult(x=b.X[:N].copy(), fun=b.F[:N].copy(), nit=b.iterations[:N].astype(int),
-                                status=b.mode[:N].astype(int), rounds=rounds, n_eval=n_eval, n_eval_fd=n_eval_fd,
-                                t_core=b.core_seconds, t_serve=t_serve)
+        requests = [None] * G          # per group: (want_f, want_g) still to be served, or None
+        alive = [True] * G
+
+        def advance(g):
+            want_f, want_g = bs[g].advance()
+            requests[g] = (want_f.copy(), want_g.copy())
+            if len(want_f) + len(want_g) == 0:
+                alive[g] = False
+
+        def serve(g):
+            nonlocal n_eval, n_eval_fd, t_serve
+            req, requests[g] = requests[g], None
+            if req is None:
+                return
+            t1 = time.perf_counter()
+            first = spans[g][0]
+            if len(req[0]):
+                self._serve(sc, bs[g], first, req[0], False)
+                n_eval += len(req[0])
+            if len(req[1]):
+                self._serve(sc, bs[g], first, req[1], True)
+                n_eval_fd += len(req[1])
+            t_serve += time.perf_counter() - t1
+
+        # every advance runs on ONE helper thread, so that the library keeps one team of host threads
+        run = self._helper.submit
+        run(advance, 0).result()
+        rounds += 1
+        cur = 0
+        while any(alive):
+            other = (cur + 1) % G
+            pending = None
+            if G > 1 and alive[other] and requests[other] is None:
+                pending = run(advance, other)  # the cores of the other half run while this half is served
+            serve(cur)
+            if pending is not None:
+                pending.result()
+                rounds += 1
+            if G == 1 or not alive[other]:
+                if alive[cur]:
+                    run(advance, cur).result()
+                    rounds += 1
+            else:
+                cur = other
+        x = np.concatenate([b.X[:cnt] for b, (_, cnt) in zip(bs, spans)])
+        cat = lambda name: np.concatenate([getattr(b, name)[:cnt] for b, (_, cnt) in zip(bs, spans)])
+        return BatchSolveResult(x=x.copy(), fun=cat("F").copy(), nit=cat("iterations").astype(int),
+                                status=cat("mode").astype(int), rounds=rounds, n_eval=n_eval, n_eval_fd=n_eval_fd,
+                                t_core=sum(b.core_seconds for b in bs), t_serve=t_serve)
 
     def close(self):
-        self.batch.close()
+        self._helper.shutdown(wait=True)
+        for b in self.batches:
+            b.close()
 
     def __enter__(self):
         return self

@@ -1,5 +1,5 @@
 """BASELINE.json configs[2] at full size: N angular-motion scenarios, H=20, one full SLSQP solve each,
-through the solver pool.  usage: solve_full.py [N] [workers] [out.json]"""
+through the solver pool.  usage: solve_full.py [N] [workers] [out.json] [native|pool]"""
 import os, sys; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import json
 import time
@@ -23,17 +23,27 @@ def main():
     hs = make_scenarios(mp, DeviceKinematics(ctx), N, motion="angular", cfg_id=3)
     t_gen = time.perf_counter() - t0
     print(f"{N} scenarios generated in {t_gen:.1f} s; {W} workers", flush=True)
-    with SolverPool(ctx, W, capacity=N) as pool:
-        solve = pool.solve
-        pool.solve = lambda sc, x0: solve(sc, x0, progress=lambda t, nf, ng, done: print(
-            f"  {t:6.1f} s: {nf} eval + {ng} eval_fd scenario-evals served, {done} workers done", flush=True), progress_every=20.0)
-        bm = BatchedMPC(ctx, solver=pool)
-        t0 = time.perf_counter()
-        u = bm.compute_control(hs.q0, hs.state0[:, 12:18], hs.target, hs.base)
-        dt = time.perf_counter() - t0
+    driver = sys.argv[4] if len(sys.argv) > 4 else "native"
+    if driver == "native":
+        from mpc_amd.native_solver import NativeBatchedSLSQP
+
+        with NativeBatchedSLSQP(ctx, threads=W, capacity=N) as native:
+            bm = BatchedMPC(ctx, solver=native)
+            t0 = time.perf_counter()
+            u = bm.compute_control(hs.q0, hs.state0[:, 12:18], hs.target, hs.base)
+            dt = time.perf_counter() - t0
+    else:
+        with SolverPool(ctx, W, capacity=N) as pool:
+            solve = pool.solve
+            pool.solve = lambda sc, x0: solve(sc, x0, progress=lambda t, nf, ng, done: print(
+                f"  {t:6.1f} s: {nf} eval + {ng} eval_fd scenario-evals served, {done} workers done", flush=True), progress_every=20.0)
+            bm = BatchedMPC(ctx, solver=pool)
+            t0 = time.perf_counter()
+            u = bm.compute_control(hs.q0, hs.state0[:, 12:18], hs.target, hs.base)
+            dt = time.perf_counter() - t0
     r = bm.last
     active = int(hs.active.sum())
-    res = {"scenarios": N, "active": active, "workers": W, "seconds": dt, "solves_per_s": active / dt,
+    res = {"scenarios": N, "active": active, "driver": driver, "workers": W, "seconds": dt, "solves_per_s": active / dt,
            "converged": int(r.success.sum()), "status_counts": {int(k): int(v) for k, v in zip(*np.unique(r.status, return_counts=True))},
            "mean_iterations": float(r.nit.mean()), "max_iterations": int(r.nit.max()), "n_eval": r.n_eval, "n_eval_fd": r.n_eval_fd,
            "max_core_seconds_per_worker": r.t_core, "server_busy_seconds": r.t_serve, "scenario_generation_seconds": t_gen,
