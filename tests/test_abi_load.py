@@ -29,6 +29,22 @@ def test_library_exports_every_declared_symbol():
     assert _ffi.load().mpc_abi_version() == _ffi.ABI_VERSION
 
 
+def test_slsqp_library_exports_every_declared_symbol():
+    """include/mpc_slsqp.h against libmpc_slsqp.so (the native host driver of the batched solves)."""
+    from mpc_amd import native_solver
+
+    text = open(os.path.join(ROOT, "include", "mpc_slsqp.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    declared = sorted(set(re.findall(r"\b(mpc_slsqp_[a-z_]+)\s*\(", text)))
+    assert len(declared) >= 12
+    if not os.path.exists(native_solver.LIB_PATH):
+        pytest.fail("libmpc_slsqp.so not built: run `python -m mpc_amd.build`")
+    lib = ctypes.CDLL(native_solver.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert native_solver.load().mpc_slsqp_abi_version() == native_solver.ABI_VERSION
+
+
 def test_struct_sizes_match_header_layout():
     # 2 int32 + 11 scalars + 3*6 limits + 4*6 DH + 2 + 3 doubles
     assert ctypes.sizeof(_ffi.MpcParamsC) == 8 + 8 * (11 + 18 + 24 + 2 + 3)
