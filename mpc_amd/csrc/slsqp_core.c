@@ -435,28 +435,6 @@ HOT static void lsi(double *e, double *f, double *g, double *h, int le, int me, 
 #undef G
 }
 
-/* Equality+inequality constrained least squares, here only for mc = 0 equality constraints
- * (the MPC problem has none): stores e, f, g in the workspace and calls lsi. */
-static void lsei_noeq(double *e, double *f, double *g, double *h, int le, int me, int lg, int mg, int n, double *x,
-                      double *xnrm, double *w, int *jw, int *mode)
-{
-    const int mc = 0;
-    int i, l, mc1, iw, ie, iff, ig;
-    *mode = 2;
-    l = n - mc;
-    mc1 = mc + 1;
-    iw = (l + 1) * (mg + 2) + 2 * mg + mc;
-    ie = iw + mc + 1;
-    iff = ie + me * l;
-    ig = iff + me;
-    *mode = 1;
-    for (i = 0; i < mg - mc; ++i) w[mc1 - 1 + i] = 0.0;
-    for (i = 1; i <= me; ++i) w[iff - 2 + i] = f[i - 1];
-    for (i = 1; i <= me; ++i) dcopy_(l, &e[(i - 1) + (mc1 - 1) * le], le, &w[ie - 2 + i], me);
-    for (i = 1; i <= mg; ++i) dcopy_(l, &g[(i - 1) + (mc1 - 1) * lg], lg, &w[ig - 2 + i], mg);
-    lsi(&w[ie - 1], &w[iff - 1], &w[ig - 1], h, me, me, mg, mg, l, &x[mc1 - 1], xnrm, &w[mc1 - 1], jw, mode);
-}
-
 /* QP subproblem in least-squares form (Kraft): e = sqrt(d) l^T, f = -d^(-1/2) l^(-1) g. */
 HOT static void lsq(int m, int meq, int n, int nl, int la, double *l, double *g, double *a, double *b, double *xl, double *xu,
                 double *x, double *y, double *w, int *jw, int *mode)
@@ -521,7 +499,11 @@ HOT static void lsq(int m, int meq, int n, int nl, int la, double *l, double *g,
     }
     (void)ic; (void)id; (void)ie;
     if (meq != 0) { *mode = 2; return; }   /* equality constraints are not part of this restatement */
-    lsei_noeq(&w[0], &w[iff - 1], &w[ig - 1], &w[ih - 1], n, n, m1, m1 - nancnt, n, x, &xnorm, &w[iw - 1], jw, mode);
+    /* No equality constraints: LSEI would only copy e, f and g once more and call LSI on the copies (they are
+     * not read again here), so LSI works on them in place; w(iw...) is LDP's workspace and returns the
+     * multipliers, as in LSEI. */
+    for (i = 0; i < m1 - nancnt; ++i) w[iw - 1 + i] = 0.0;
+    lsi(&w[0], &w[iff - 1], &w[ig - 1], &w[ih - 1], n, n, m1, m1 - nancnt, n, x, &xnorm, &w[iw - 1], jw, mode);
     if (*mode == 1) {
         dcopy_(m, &w[iw - 1], 1, y, 1);
         if (n3 > 0) {
