@@ -41,7 +41,8 @@ def _scipy_core_solve(co, hs, i, mp, lb, ub, x0):
     return p, hist
 
 
-@pytest.mark.parametrize("H,N,motion,prev", [(1, 12, "linear", False), (3, 10, "angular", True), (20, 5, "angular", False)])
+@pytest.mark.parametrize("H,N,motion,prev", [(1, 12, "linear", False), (3, 10, "angular", True), (20, 5, "angular", False),
+                                            (40, 2, "linear", True)])
 def test_native_batch_reproduces_scipy_core_call_by_call(H, N, motion, prev):
     """Every round of the native driver leaves every problem exactly where scipy's core leaves it after the
     same number of calls: same mode, bit-identical x; same exit mode, iteration count and f at the end."""
