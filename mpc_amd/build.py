@@ -73,12 +73,24 @@ def build_slsqp(force: bool = False, verbose: bool = False) -> str:
         raise RuntimeError("gcc not found: libmpc_slsqp.so cannot be built")
     srcs = [os.path.join(CSRC, u) for u in _SLSQP_UNITS]
     deps = srcs + [os.path.join(CSRC, "slsqp_core.h"), os.path.join(_ROOT, "include", "mpc_slsqp.h")]
-    if force or _stale(SLSQP_LIB_PATH, deps):
-        cmd = [gcc] + _SLSQP_FLAGS + ["-shared", "-I" + os.path.join(_ROOT, "include"), "-I" + CSRC, "-o", SLSQP_LIB_PATH] \
-            + srcs + ["-lm"]
-        if verbose:
-            print(" ".join(cmd), flush=True)
-        subprocess.check_call(cmd)
+    spmd = [os.path.join(CSRC, "lsq_spmd_host.cpp"), os.path.join(CSRC, "lsq_spmd.hpp")]
+    if force or _stale(SLSQP_LIB_PATH, deps + spmd):
+        objdir = os.path.join(_HERE, "build")
+        os.makedirs(objdir, exist_ok=True)
+        inc = ["-I" + os.path.join(_ROOT, "include"), "-I" + CSRC]
+        spmd_obj = os.path.join(objdir, "lsq_spmd_host.o")
+        gxx = shutil.which("g++") or gcc
+        cmds = [[gxx, "-O2", "-ffp-contract=off", "-fPIC", "-std=c++17", "-Wall"] + inc + ["-c", spmd[0], "-o", spmd_obj]]
+        c_objs = []
+        for src in srcs:
+            obj = os.path.join(objdir, os.path.basename(src)[:-2] + ".o")
+            c_objs.append(obj)
+            cmds.append([gcc] + _SLSQP_FLAGS + inc + ["-c", src, "-o", obj])
+        cmds.append([gxx, "-shared", "-fopenmp", "-o", SLSQP_LIB_PATH] + c_objs + [spmd_obj, "-lm"])
+        for cmd in cmds:
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            subprocess.check_call(cmd)
     return SLSQP_LIB_PATH
 
 

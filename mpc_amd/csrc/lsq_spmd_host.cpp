@@ -1,0 +1,35 @@
+// Host instantiation of the team-parallel LSQ (lsq_spmd.hpp) with a team of one, behind the signature of
+// slsqp_core.c's lsq: tests install it with mpc_slsqp_set_lsq and require whole solves to stay bit-identical.
+#include <cmath>
+#include <cstdlib>
+#include <vector>
+
+#include "lsq_spmd.hpp"
+#include "slsqp_core.h"
+
+extern "C" void mpc_lsq_spmd_serial(int m, int meq, int n, int nl, int la, double *l, double *g, double *a, double *b,
+                                    double *xl, double *xu, double *x, double *y, double *w, int *jw, int *mode)
+{
+    const int H = n / 6;
+    if (meq != 0 || n != 6 * H || m != 12 * (H + 1) || nl != (n + 1) * n / 2 + 1) {   // e.g. the augmented problem
+        mpc_slsqp_lsq_builtin(m, meq, n, nl, la, l, g, a, b, xl, xu, x, y, w, jw, mode);
+        return;
+    }
+    const int nzc = 6 * H + 3 * H * (H + 1), mg = m + 2 * n;
+    std::vector<double> nz(nzc), dw(lsqspmd::work_doubles(n, m, 1)), yy(mg);
+    std::vector<int> iw(lsqspmd::work_ints(n, m, 1));
+    for (int j = 0; j < H; ++j) {
+        const int tri = j * H - (j * (j - 1)) / 2 - j - 1;
+        for (int q = 0; q < 6; ++q) {
+            const int col = 6 * j + q;
+            nz[col] = a[(12 * (j + 1) + 6 + q) + (size_t)col * la];
+            for (int k = j + 1; k <= H; ++k) nz[6 * H + 6 * (tri + k) + q] = a[(12 * k + q) + (size_t)col * la];
+        }
+    }
+    lsqspmd::Work W = lsqspmd::carve(dw.data(), iw.data(), n, m, 1);
+    *mode = lsqspmd::lsq(lsqspmd::SerialTeam(), W, H, l, g, b, nz.data(), xl, xu, x, yy.data());
+    if (*mode == 1) {
+        for (int i = 0; i < m; ++i) y[i] = yy[i];
+        for (int i = m; i < m + 2 * n; ++i) y[i] = NAN;
+    }
+}

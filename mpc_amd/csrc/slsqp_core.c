@@ -517,6 +517,23 @@ HOT static void lsq(int m, int meq, int n, int nl, int la, double *l, double *g,
     }
 }
 
+static mpc_lsq_fn lsq_hook = 0;
+
+void mpc_slsqp_lsq_builtin(int m, int meq, int n, int nl, int la, double *l, double *g, double *a, double *b, double *xl,
+                           double *xu, double *x, double *y, double *w, int *jw, int *mode)
+{
+    lsq(m, meq, n, nl, la, l, g, a, b, xl, xu, x, y, w, jw, mode);
+}
+
+void mpc_slsqp_set_lsq(mpc_lsq_fn fn) { lsq_hook = fn; }
+
+static void lsq_dispatch(int m, int meq, int n, int nl, int la, double *l, double *g, double *a, double *b, double *xl,
+                         double *xu, double *x, double *y, double *w, int *jw, int *mode)
+{
+    if (lsq_hook) lsq_hook(m, meq, n, nl, la, l, g, a, b, xl, xu, x, y, w, jw, mode);
+    else lsq(m, meq, n, nl, la, l, g, a, b, xl, xu, x, y, w, jw, mode);
+}
+
 /* Rank-one update of an LDL^T factorisation (Fletcher & Powell). */
 static void ldl(int n, double *a, double *z, double sigma, double *w)
 {
@@ -611,7 +628,7 @@ L130:
     daxpy_sl(n, -1.0, x, 1, u, 1);
     daxpy_sl(n, -1.0, x, 1, v, 1);
     h4 = 1.0;
-    lsq(m, meq, n, n3, la, l, g, a, c, u, v, s, r, w, iw, mode);
+    lsq_dispatch(m, meq, n, n3, la, l, g, a, c, u, v, s, r, w, iw, mode);
     badlin = 0;
     if (*mode == 6 && n == meq) *mode = 4;
     if (*mode == 4) {
@@ -626,7 +643,7 @@ L130:
         v[n1 - 1] = 1.0;
         incons = 0;
     L150:
-        lsq(m, meq, n1, n3, la, l, g, a, c, u, v, s, r, w, iw, mode);
+        lsq_dispatch(m, meq, n1, n3, la, l, g, a, c, u, v, s, r, w, iw, mode);
         h4 = 1.0 - s[n1 - 1];
         if (*mode == 4) {
             l[n3 - 1] = 10.0 * l[n3 - 1];

@@ -20,6 +20,15 @@ void mpc_slsqpb(int m, int meq, int la, int n, double *x, double *xl, double *xu
                 double *a, double *acc, int *iter, int *mode, double *r, double *l, double *x0, double *mu, double *s,
                 double *u, double *v, double *w, int *iw, slsqp_state *S);
 
+/* The QP subproblem alone (Kraft's LSQ), and a hook that replaces it inside mpc_slsqpb: the way the
+ * team-parallel restatement (lsq_spmd.hpp, the form a GPU workgroup runs) is checked against this file
+ * over whole solves.  NULL restores the built-in routine.  Process-wide; meant for tests. */
+typedef void (*mpc_lsq_fn)(int m, int meq, int n, int nl, int la, double *l, double *g, double *a, double *b, double *xl,
+                           double *xu, double *x, double *y, double *w, int *jw, int *mode);
+void mpc_slsqp_lsq_builtin(int m, int meq, int n, int nl, int la, double *l, double *g, double *a, double *b, double *xl,
+                           double *xu, double *x, double *y, double *w, int *jw, int *mode);
+void mpc_slsqp_set_lsq(mpc_lsq_fn fn);
+
 /* Same call with scipy's single workspace array (layout of the Fortran driver SLSQP), for side-by-side tests. */
 void mpc_slsqp_step(int m, int meq, int la, int n, double *x, double *xl, double *xu, double f, double *c, double *g,
                     double *a, double *acc, int *iter, int *mode, double *w, int l_w, int *jw, int l_jw, slsqp_state *S);

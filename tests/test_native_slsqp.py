@@ -95,3 +95,55 @@ def test_native_batch_argument_checks():
     b.begin(np.full((2, 6), 5.0), -np.ones(6), np.ones(6), 1e-3, 50)
     np.testing.assert_array_equal(b.X, np.ones((2, 6)))                   # start point clipped to the bounds
     b.close()
+
+
+@pytest.mark.parametrize("H,N", [(1, 8), (3, 8), (20, 4)])
+def test_team_parallel_lsq_with_a_team_of_one_keeps_whole_solves_identical(H, N):
+    """lsq_spmd.hpp is the QP subproblem written for a team of threads (the form a GPU workgroup runs).  With a
+    team of one, hooked into the C core in place of its own LSQ, whole solves must not move by a bit."""
+    import ctypes
+
+    from mpc_amd import native_solver
+
+    lib = native_solver.load()
+    mp = params_for(H)
+    co, hs = host_scenarios(mp, N, motion="angular", cfg_id=42, goal_jitter=0.0 if H == 20 else 0.05)
+    n = mp.n
+    lb = np.array([b[0] for b in mp.bounds()])
+    ub = np.array([b[1] for b in mp.bounds()])
+    scatter = nz_scatter_index(H)
+
+    def solve():
+        b = NativeBatch(H, N, threads=1)
+        b.begin(np.tile(hs.u_init, (1, H)), lb, ub, mp.ftol, mp.maxiter)
+        f, g, c, a = co.eval_fd(_rows(hs, np.arange(N), b.X[:N]))
+        b.F[:N], b.Cc[:N], b.G[:N, :n], b.NZ[:N] = f, c, g, a.reshape(N, -1)[:, scatter]
+        trace = []
+        while True:
+            wf, wg = (w.copy() for w in b.advance())
+            trace.append((b.X[:N].copy(), b.mode[:N].copy()))
+            if len(wf) + len(wg) == 0:
+                break
+            if len(wf):
+                f, c = co.eval(_rows(hs, wf, np.clip(b.X[wf], lb, ub)))
+                b.F[wf], b.Cc[wf] = f, c
+            if len(wg):
+                _, g, _, a = co.eval_fd(_rows(hs, wg, np.clip(b.X[wg], lb, ub)))
+                b.G[wg, :n] = g
+                b.NZ[wg] = a.reshape(len(wg), -1)[:, scatter]
+        out = (trace, b.iterations[:N].copy(), b.F[:N].copy())
+        b.close()
+        return out
+
+    want = solve()
+    lib.mpc_slsqp_set_lsq(ctypes.cast(lib.mpc_lsq_spmd_serial, ctypes.c_void_p))
+    try:
+        got = solve()
+    finally:
+        lib.mpc_slsqp_set_lsq(None)
+    assert len(got[0]) == len(want[0])
+    for (xa, ma), (xb, mb) in zip(got[0], want[0]):
+        np.testing.assert_array_equal(ma, mb)
+        np.testing.assert_array_equal(xa, xb)
+    np.testing.assert_array_equal(got[1], want[1])
+    np.testing.assert_array_equal(got[2], want[2])
