@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MPC_AMD_ABI_VERSION 3
+#define MPC_AMD_ABI_VERSION 4
 #define MPC_MAX_HORIZON 255
 
 typedef enum mpc_status {
@@ -168,6 +168,18 @@ int mpc_prepare_tick(mpc_ctx *ctx, int count, const double *q, const double *dq,
                      const double *base, const double *dyn_host, const double *prev_solution,
                      const uint8_t *has_solution, double *state0, double *base_traj, double *Jc, double *u_init,
                      double *x0, uint8_t *active, void *stream);
+
+/* The QP subproblem of one SLSQP major iteration (what scipy's compiled core spends its time in; called
+ * from _slsqp_py.py:429 via the Fortran LSQ) for `count` problems, one workgroup each:
+ *   minimise || e s - f ||, e = sqrt(d) l^T, f = -d^(-1/2) l^(-1) g   (l: packed LDL' factor of the BFGS matrix,
+ *   [(n+1)n/2 + 1] per problem, g [n] the gradient), subject to c + (dc/dx) s >= 0 (c [m], dc/dx in the
+ *   structured form nz of mpc_eval_fd_nz) and lo <= s <= hi ([n] each: the box around the iterate).
+ * Outputs: s [count][n] the step, y [count][m + 2n] the multipliers (constraint rows first), mode [count]
+ * (1 = solved, otherwise the code the SLSQP body hands on, 4 = inconsistent linearisation).  The arithmetic
+ * is the host core's (mpc_amd/csrc/slsqp_core.c), entry for entry, so results are bit-identical to it and to
+ * scipy's.  All pointers are device pointers.  Needs a context whose horizon matches. */
+int mpc_qp_solve(mpc_ctx *ctx, int count, const double *l, const double *g, const double *c, const double *nz,
+                 const double *lo, const double *hi, double *s, double *y, int32_t *mode, void *stream);
 
 /* Active-set gather for lock-step solves: scipy's driver evaluates a problem only when its SLSQP core
  * asks (mode 1 / -1, _slsqp_py.py:427-456), so each round of a batched solve touches a changing subset

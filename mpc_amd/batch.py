@@ -242,6 +242,25 @@ class MpcContext:
             self._stream()))
         return sc, u_init, x0, active
 
+    def qp_solve(self, l: torch.Tensor, g: torch.Tensor, c: torch.Tensor, nz: torch.Tensor, lo: torch.Tensor,
+                 hi: torch.Tensor):
+        """SLSQP's QP subproblem for a batch (include/mpc_amd.h, mpc_qp_solve): returns (s [N,n], y [N,m+2n],
+        mode [N] int32)."""
+        N = int(g.shape[0])
+        ldl = (self.n + 1) * self.n // 2 + 1
+        lp = self._chk(l, (N, ldl), "l")
+        gp = self._chk(g, (N, self.n), "g")
+        cp = self._chk(c, (N, self.m), "c")
+        zp = self._chk(nz, (N, self.nz_count), "nz")
+        lop = self._chk(lo, (N, self.n), "lo")
+        hip_ = self._chk(hi, (N, self.n), "hi")
+        s = self._new(N, self.n)
+        y = self._new(N, self.m + 2 * self.n)
+        mode = torch.zeros(N, dtype=torch.int32, device=self.device)
+        _ffi.check(self._ctx, self._lib.mpc_qp_solve(self._ctx, N, lp, gp, cp, zp, lop, hip_, s.data_ptr(), y.data_ptr(),
+                                                     mode.data_ptr(), self._stream()))
+        return s, y, mode
+
     def gather(self, src: ScenarioBatch, index: torch.Tensor, out: ScenarioBatch) -> ScenarioBatch:
         """Rows ``index`` (int32 device tensor [k], values in [0, src.count)) of ``src`` -> the first k
         rows of ``out`` in one launch; returns that k-row view of ``out``."""

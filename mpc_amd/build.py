@@ -22,6 +22,7 @@ _UNITS = {
     "kernels_rollout.hip": _STRICT,
     "kernels_aux.hip": _STRICT,
     "kernels_prefix.hip": _STRICT,  # fused multiply-adds are written out with fma() there
+    "kernels_qp.hip": _STRICT,      # bit-identical to the host SLSQP core
 }
 _COMMON = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function",
            "-I" + os.path.join(_ROOT, "include"), "-I" + CSRC]

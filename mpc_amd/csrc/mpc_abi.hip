@@ -22,6 +22,9 @@ struct mpc_ctx {
     double *d_work = nullptr;   // long-horizon MPC_ALGO_PREFIX: FD quotients between its two kernels
     size_t work_doubles = 0;
     mpck::PrefixPipeline pipe;  // second stream + events: overlaps the two long-horizon kernels
+    double *d_qp_work = nullptr;  // mpc_qp_solve: workspace of the resident workgroups (allocated on first use)
+    int *d_qp_iwork = nullptr;
+    int qp_teams = 0;
     char err[512] = {0};
 };
 
@@ -124,6 +127,8 @@ void mpc_ctx_destroy(mpc_ctx *ctx)
     if (ctx->d_decay) (void)hipFree(ctx->d_decay);
     if (ctx->d_fvals) (void)hipFree(ctx->d_fvals);
     if (ctx->d_work) (void)hipFree(ctx->d_work);
+    if (ctx->d_qp_work) (void)hipFree(ctx->d_qp_work);
+    if (ctx->d_qp_iwork) (void)hipFree(ctx->d_qp_iwork);
     for (int h = 0; h < 2; ++h) {
         if (ctx->pipe.filled[h]) (void)hipEventDestroy(ctx->pipe.filled[h]);
         if (ctx->pipe.drained[h]) (void)hipEventDestroy(ctx->pipe.drained[h]);
@@ -321,6 +326,40 @@ int mpc_prepare_tick(mpc_ctx *ctx, int count, const double *q, const double *dq,
     MPC_HIP(ctx, mpck::launch_prepare_tick(ctx->params, count, dyn, q, dq, ee_pose, base, prev_solution, has_solution,
                                            state0, base_traj, Jc, u_init, x0, active,
                                            static_cast<hipStream_t>(stream)));
+    return MPC_OK;
+}
+
+int mpc_qp_solve(mpc_ctx *ctx, int count, const double *l, const double *g, const double *c, const double *nz,
+                 const double *lo, const double *hi, double *s, double *y, int32_t *mode, void *stream)
+{
+    int rc = check_ready(ctx);
+    if (rc) return rc;
+    if (count < 0 || count > ctx->max_scenarios)
+        return fail(ctx, MPC_ERR_INVALID_ARG, "count %d outside [0, %d]", count, ctx->max_scenarios);
+    if (count == 0) return MPC_OK;
+    if (!l || !g || !c || !nz || !lo || !hi || !s || !y || !mode)
+        return fail(ctx, MPC_ERR_INVALID_ARG, "l/g/c/nz/lo/hi/s/y/mode must be non-NULL");
+    MPC_HIP(ctx, hipSetDevice(ctx->device));
+    if (!ctx->d_qp_work) {
+        // up to four resident workgroups per CU; each owns ~1.1 MB of workspace at H = 20
+        hipDeviceProp_t prop;
+        MPC_HIP(ctx, hipGetDeviceProperties(&prop, ctx->device));
+        int teams = 4 * prop.multiProcessorCount;
+        if (teams > ctx->max_scenarios) teams = ctx->max_scenarios;
+        const size_t wd = mpck::qp_work_doubles(ctx->horizon), wi = mpck::qp_work_ints(ctx->horizon);
+        while (teams > 1 && (size_t)teams * wd * sizeof(double) > (size_t(4) << 30)) teams /= 2;
+        MPC_HIP(ctx, hipMalloc(&ctx->d_qp_work, (size_t)teams * wd * sizeof(double)));
+        hipError_t e = hipMalloc(&ctx->d_qp_iwork, (size_t)teams * wi * sizeof(int));
+        if (e != hipSuccess) {
+            (void)hipFree(ctx->d_qp_work);
+            ctx->d_qp_work = nullptr;
+            return hip_fail(ctx, e, "hipMalloc(qp iwork)");
+        }
+        ctx->qp_teams = teams;
+    }
+    const int teams = count < ctx->qp_teams ? count : ctx->qp_teams;
+    MPC_HIP(ctx, mpck::launch_qp(ctx->horizon, count, teams, l, g, c, nz, lo, hi, s, y, mode, ctx->d_qp_work, ctx->d_qp_iwork,
+                                 static_cast<hipStream_t>(stream)));
     return MPC_OK;
 }
 

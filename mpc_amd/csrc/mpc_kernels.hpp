@@ -52,6 +52,15 @@ hipError_t launch_prepare_tick(const mpc_params &P, int N, const double (&dyn)[6
                                const uint8_t *has_solution, double *state0, double *base_traj, double *Jc,
                                double *u_init, double *x0, uint8_t *active, hipStream_t stream);
 
+// SLSQP's QP subproblem, one workgroup per problem (kernels_qp.hip).  `teams` workgroups share the batch;
+// work / iwork hold teams * qp_work_doubles(H) doubles / teams * qp_work_ints(H) ints.
+constexpr int kQpThreads = 256;
+size_t qp_work_doubles(int H);
+size_t qp_work_ints(int H);
+hipError_t launch_qp(int H, int count, int teams, const double *l, const double *g, const double *c, const double *nz,
+                     const double *lo, const double *hi, double *s, double *y, int32_t *mode, double *work, int *iwork,
+                     hipStream_t stream);
+
 // dst row i = src row index[i] for every scenario array (NaN rows for an index outside [0, src.count))
 hipError_t launch_gather_scenarios(int H, const mpc_scenarios &src, const int32_t *index, int count,
                                    const mpc_scenarios &dst, hipStream_t stream);

@@ -349,3 +349,75 @@ def test_native_driver_equals_scipy_core_driver():
                 ua = a.compute_control(hs.q0, hs.state0[:, 12:18], hs.target, hs.base)
                 ub = b.compute_control(hs.q0, hs.state0[:, 12:18], hs.target, hs.base)
                 np.testing.assert_array_equal(ub, ua)
+
+
+@pytest.mark.parametrize("H,N", [(1, 6), (3, 6), (20, 3)])
+def test_qp_subproblem_on_the_device_is_bit_identical_to_the_host_core(H, N):
+    """Every QP subproblem that whole host solves pose (recorded through the core's LSQ hook: LDL' factor,
+    gradient, constraint values, structured dc/dx, box) is solved again by mpc_qp_solve, one workgroup per
+    problem: same step, same constraint multipliers, same mode, bit for bit."""
+    import ctypes
+
+    from helpers import host_scenarios
+    from mpc_amd import native_solver
+    from mpc_amd.batch import MpcContext
+    from mpc_amd.native_solver import NativeBatch
+    from mpc_amd.slsqp_state import nz_scatter_index
+
+    lib = native_solver.load()
+    mp = MpcParams.reference_yaml_defaults(horizon=H)
+    co, hs = host_scenarios(mp, N, motion="angular", cfg_id=43, goal_jitter=0.0 if H == 20 else 0.05)
+    n, m = mp.n, mp.m
+    lb = np.array([b[0] for b in mp.bounds()])
+    ub = np.array([b[1] for b in mp.bounds()])
+    scatter = nz_scatter_index(H)
+    ldl = (n + 1) * n // 2 + 1
+    dp, ip = ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int)
+    FN = ctypes.CFUNCTYPE(None, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, dp, dp, dp, dp, dp, dp,
+                          dp, dp, dp, ip, ip)
+    builtin = FN(("mpc_slsqp_lsq_builtin", lib))
+    rec = []
+
+    def hook(m_, meq, n_, nl, la, l, g, a, b, xl, xu, x, y, w, jw, mode):
+        arr = lambda p, k: np.ctypeslib.as_array(p, shape=(k,)).copy()
+        inp = None
+        if n_ == n and nl == ldl:
+            inp = (arr(l, ldl), arr(g, n), arr(b, m_), arr(a, (n + 1) * la)[scatter], arr(xl, n), arr(xu, n))
+        builtin(m_, meq, n_, nl, la, l, g, a, b, xl, xu, x, y, w, jw, mode)
+        if inp is not None:
+            rec.append(inp + (arr(x, n), arr(y, m_), mode[0]))
+
+    cb = FN(hook)
+    lib.mpc_slsqp_set_lsq(ctypes.cast(cb, ctypes.c_void_p))
+    try:
+        def rows(idx, X):
+            d = {k: (None if v is None else v[idx]) for k, v in hs.as_oracle_dict().items()}
+            d["x"] = np.ascontiguousarray(X)
+            return d
+        b = NativeBatch(H, N, threads=1)
+        b.begin(np.tile(hs.u_init, (1, H)), lb, ub, mp.ftol, mp.maxiter)
+        f, g, c, a = co.eval_fd(rows(np.arange(N), b.X[:N]))
+        b.F[:N], b.Cc[:N], b.G[:N, :n], b.NZ[:N] = f, c, g, a.reshape(N, -1)[:, scatter]
+        while True:
+            wf, wg = (w.copy() for w in b.advance())
+            if len(wf) + len(wg) == 0:
+                break
+            if len(wf):
+                f, c = co.eval(rows(wf, np.clip(b.X[wf], lb, ub)))
+                b.F[wf], b.Cc[wf] = f, c
+            if len(wg):
+                _, g, _, a = co.eval_fd(rows(wg, np.clip(b.X[wg], lb, ub)))
+                b.G[wg, :n] = g
+                b.NZ[wg] = a.reshape(len(wg), -1)[:, scatter]
+        b.close()
+    finally:
+        lib.mpc_slsqp_set_lsq(None)
+    K = len(rec)
+    assert K >= N
+    ctx = MpcContext(mp, max(K, 8), 0)
+    up = lambda k: torch.as_tensor(np.stack([r[k] for r in rec])).to(ctx.device)
+    s, y, mode = ctx.qp_solve(up(0), up(1), up(2), up(3), up(4), up(5))
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(mode.cpu().numpy(), np.array([r[8] for r in rec]))
+    np.testing.assert_array_equal(s.cpu().numpy(), np.stack([r[6] for r in rec]))
+    np.testing.assert_array_equal(y.cpu().numpy()[:, :m], np.stack([r[7] for r in rec]))
