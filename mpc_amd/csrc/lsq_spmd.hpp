@@ -504,4 +504,142 @@ SPMD_HD int lsq(const Team &T, const Work &W, int H, const double *l, const doub
 #undef G
 }
 
+// Rank-one update of the LDL' factorisation a (packed by columns) with z and sigma; w is work (Fletcher &
+// Powell's composite-t method as in slsqp_core.c's ldl).  The outer recurrence runs in step on every thread
+// (each recomputes the scalars from values that are final after the previous barrier); the inner loops
+// over the rows below the diagonal are the parallel part.  New diagonals are parked in W.acc[n..2n) and
+// written back at the end, so that no thread reads a diagonal another one is replacing.
+template <class Team>
+SPMD_HD void ldl(const Team &T, const Work &W, int n, double *a, double *z, double sigma, double *w)
+{
+    if (sigma == 0.0) return;
+    double *dnew = W.acc + n;
+    double t = 1.0 / sigma;
+    int ij = 1;
+    if (sigma <= 0.0) {
+        PAR_FOR(T, i, 0, n) w[i] = z[i];
+        T.sync();
+        for (int i = 1; i <= n; ++i) {
+            const double v = w[i - 1];
+            t = t + v * v / a[ij - 1];
+            PAR_FOR(T, j, i + 1, n + 1) w[j - 1] = w[j - 1] - v * a[ij - 1 + (j - i)];
+            T.sync();
+            ij = ij + (n - i) + 1;
+        }
+        if (t >= 0.0) t = 2.22e-16 / sigma;
+        if (T.tid() == 0) {
+            int q = ij;
+            double tt = t;
+            for (int i = 1; i <= n; ++i) {
+                const int j = n + 1 - i;
+                q = q - i;
+                const double u = w[j - 1];
+                w[j - 1] = tt;
+                tt = tt - u * u / a[q - 1];
+            }
+            W.sc[4] = tt;
+        }
+        T.sync();
+        t = W.sc[4];
+        ij = ij - (n * (n + 1)) / 2;
+        T.sync();
+    }
+    for (int i = 1; i <= n; ++i) {
+        const double v = z[i - 1], aij = a[ij - 1];
+        const double delta = v / aij;
+        double tp = 0.0;
+        if (sigma < 0.0) tp = w[i - 1];
+        if (sigma > 0.0) tp = t + delta * v;
+        const double alpha = tp / t;
+        if (T.tid() == 0) dnew[i - 1] = alpha * aij;
+        if (i == n) break;
+        const double beta = delta / tp;
+        if (alpha > 4.0) {
+            const double gamma = t / tp;
+            PAR_FOR(T, j, i + 1, n + 1) {
+                const int p = ij - 1 + (j - i);
+                const double u = a[p];
+                a[p] = gamma * u + beta * z[j - 1];
+                z[j - 1] = z[j - 1] - v * u;
+            }
+        } else {
+            PAR_FOR(T, j, i + 1, n + 1) {
+                const int p = ij - 1 + (j - i);
+                z[j - 1] = z[j - 1] - v * a[p];
+                a[p] = a[p] + beta * z[j - 1];
+            }
+        }
+        T.sync();
+        ij = ij + (n - i) + 1;
+        t = tp;
+    }
+    T.sync();
+    PAR_FOR(T, i, 0, n) a[i * n - (i * (i - 1)) / 2] = dnew[i];
+    T.sync();
+}
+
+// The modified BFGS update of SLSQP's major iteration (the block after the derivatives arrive, before the
+// next QP): u = g - (dc/dx)^T r - v, v = L D L' s, damping, then two rank-one updates of l.
+// v holds the previous Lagrangian gradient on entry and is scratch afterwards; u [n] is scratch.
+template <class Team>
+SPMD_HD void bfgs_update(const Team &T, const Work &W, int H, double *l, const double *g, const double *nz, const double *r,
+                         double *v, const double *s, double *u)
+{
+    const int n = 6 * H;
+    double *vold = W.acc;
+    PAR_FOR(T, i, 0, n) {
+        const int j = i / 6, a = i % 6;
+        const int tri = j * H - (j * (j - 1)) / 2 - j - 1;
+        double t = 0.0;                                   // column i of dc/dx times r, rows in ascending order
+        for (int kk = j + 1; kk <= H; ++kk) {
+            t = t + nz[6 * H + 6 * (tri + kk) + a] * r[12 * kk + a];
+            if (kk == j + 1) t = t + nz[i] * r[12 * (j + 1) + 6 + a];
+        }
+        u[i] = g[i] - t - v[i];
+    }
+    T.sync();
+    PAR_FOR(T, i, 0, n) {
+        const int off = i * n - (i * (i - 1)) / 2;
+        double h1 = 0.0;
+        for (int j = i + 1; j < n; ++j) h1 = h1 + l[off + (j - i)] * s[j];
+        double vi = s[i] + h1;
+        vi = l[off] * vi;
+        vold[i] = vi;
+    }
+    T.sync();
+    PAR_FOR(T, i, 0, n) {
+        double h1 = 0.0;
+        for (int j = 0; j < i; ++j) h1 = h1 + l[j * n - (j * (j - 1)) / 2 + (i - j)] * vold[j];
+        v[i] = vold[i] + h1;
+    }
+    T.sync();
+    if (T.tid() == 0) {
+        double h1 = 0.0, h2 = 0.0;
+        for (int i = 0; i < n; ++i) h1 = h1 + s[i] * u[i];
+        for (int i = 0; i < n; ++i) h2 = h2 + s[i] * v[i];
+        const double h3 = 0.2 * h2;
+        double h4 = 0.0;
+        int damp = 0;
+        if (h1 < h3) {
+            h4 = (h2 - h3) / (h2 - h1);
+            h1 = h3;
+            damp = 1;
+        }
+        W.sc[5] = h1; W.sc[6] = h2; W.sc[7] = h4; W.isc[10] = damp;
+    }
+    T.sync();
+    const double h1 = W.sc[5], h2 = W.sc[6], h4 = W.sc[7];
+    if (W.isc[10]) {
+        const double da = 1.0 - h4;
+        PAR_FOR(T, i, 0, n) {
+            double ui = h4 * u[i];
+            if (da != 0.0) ui = ui + da * v[i];
+            u[i] = ui;
+        }
+        T.sync();
+    }
+    ldl(T, W, n, l, u, +1.0 / h1, v);
+    ldl(T, W, n, l, v, -1.0 / h2, u);
+}
+
 }  // namespace lsqspmd

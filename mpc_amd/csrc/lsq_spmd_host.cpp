@@ -33,3 +33,26 @@ extern "C" void mpc_lsq_spmd_serial(int m, int meq, int n, int nl, int la, doubl
         for (int i = m; i < m + 2 * n; ++i) y[i] = NAN;
     }
 }
+
+extern "C" void mpc_bfgs_spmd_serial(int m, int n, int la, double *l, double *g, double *a, double *r, double *u, double *v,
+                                     double *s)
+{
+    const int H = n / 6;
+    if (n != 6 * H || m != 12 * (H + 1)) {
+        mpc_slsqp_bfgs_builtin(m, n, la, l, g, a, r, u, v, s);
+        return;
+    }
+    const int nzc = 6 * H + 3 * H * (H + 1);
+    std::vector<double> nz(nzc), dw(lsqspmd::work_doubles(n, m, 1));
+    std::vector<int> iw(lsqspmd::work_ints(n, m, 1));
+    for (int j = 0; j < H; ++j) {
+        const int tri = j * H - (j * (j - 1)) / 2 - j - 1;
+        for (int q = 0; q < 6; ++q) {
+            const int col = 6 * j + q;
+            nz[col] = a[(12 * (j + 1) + 6 + q) + (size_t)col * la];
+            for (int k = j + 1; k <= H; ++k) nz[6 * H + 6 * (tri + k) + q] = a[(12 * k + q) + (size_t)col * la];
+        }
+    }
+    lsqspmd::Work W = lsqspmd::carve(dw.data(), iw.data(), n, m, 1);
+    lsqspmd::bfgs_update(lsqspmd::SerialTeam(), W, H, l, g, nz.data(), r, v, s, u);
+}

@@ -589,13 +589,55 @@ static void ldl(int n, double *a, double *z, double sigma, double *w)
 }
 
 
+static mpc_bfgs_fn bfgs_hook = 0;
+
+void mpc_slsqp_set_bfgs(mpc_bfgs_fn fn) { bfgs_hook = fn; }
+
+/* Modified BFGS update of the LDL' factor l (Powell's damping), the block of the body that follows a
+ * derivative evaluation. */
+void mpc_slsqp_bfgs_builtin(int m, int n, int la, double *l, double *g, double *a, double *r, double *u, double *v, double *s)
+{
+#define A(i, j) a[((i) - 1) + ((j) - 1) * la]
+    const int n1 = n + 1;
+    int i, j, k;
+    double h1, h2, h3, h4;
+    for (i = 1; i <= n; ++i) u[i - 1] = g[i - 1] - ddot_sl(m, &A(1, i), 1, r, 1) - v[i - 1];
+    k = 0;
+    for (i = 1; i <= n; ++i) {
+        h1 = 0.0;
+        k = k + 1;
+        for (j = i + 1; j <= n; ++j) { k = k + 1; h1 = h1 + l[k - 1] * s[j - 1]; }
+        v[i - 1] = s[i - 1] + h1;
+    }
+    k = 1;
+    for (i = 1; i <= n; ++i) { v[i - 1] = l[k - 1] * v[i - 1]; k = k + n1 - i; }
+    for (i = n; i >= 1; --i) {
+        h1 = 0.0;
+        k = i;
+        for (j = 1; j <= i - 1; ++j) { h1 = h1 + l[k - 1] * v[j - 1]; k = k + n - j; }
+        v[i - 1] = v[i - 1] + h1;
+    }
+    h1 = ddot_sl(n, s, 1, u, 1);
+    h2 = ddot_sl(n, s, 1, v, 1);
+    h3 = 0.2 * h2;
+    if (h1 < h3) {
+        h4 = (h2 - h3) / (h2 - h1);
+        h1 = h3;
+        dscal_sl(n, h4, u, 1);
+        daxpy_sl(n, 1.0 - h4, v, 1, u, 1);
+    }
+    ldl(n, l, u, +1.0 / h1, v);
+    ldl(n, l, v, -1.0 / h2, u);
+#undef A
+}
+
 void mpc_slsqpb(int m, int meq, int la, int n, double *x, double *xl, double *xu, double f, double *c, double *g, double *a,
                    double *acc, int *iter, int *mode, double *r, double *l, double *x0, double *mu, double *s, double *u,
                    double *v, double *w, int *iw, slsqp_state *S)
 {
 #define A(i, j) a[((i) - 1) + ((j) - 1) * la]
     const double alfmin = 0.1;
-    int i, j, k, badlin = 0;
+    int i, j, badlin = 0;
     double alpha = S->alpha, f0 = S->f0, gs = S->gs, h1 = S->h1, h2 = S->h2, h3 = S->h3, h4 = S->h4, t = S->t, t0 = S->t0,
            tol = S->tol;
     int iexact = S->iexact, incons = S->incons, ireset = S->ireset, itermx = S->itermx, line = S->line, n1 = S->n1,
@@ -718,33 +760,8 @@ L255:
     else *mode = 8;
     goto L330;
 L260:
-    for (i = 1; i <= n; ++i) u[i - 1] = g[i - 1] - ddot_sl(m, &A(1, i), 1, r, 1) - v[i - 1];
-    k = 0;
-    for (i = 1; i <= n; ++i) {
-        h1 = 0.0;
-        k = k + 1;
-        for (j = i + 1; j <= n; ++j) { k = k + 1; h1 = h1 + l[k - 1] * s[j - 1]; }
-        v[i - 1] = s[i - 1] + h1;
-    }
-    k = 1;
-    for (i = 1; i <= n; ++i) { v[i - 1] = l[k - 1] * v[i - 1]; k = k + n1 - i; }
-    for (i = n; i >= 1; --i) {
-        h1 = 0.0;
-        k = i;
-        for (j = 1; j <= i - 1; ++j) { h1 = h1 + l[k - 1] * v[j - 1]; k = k + n - j; }
-        v[i - 1] = v[i - 1] + h1;
-    }
-    h1 = ddot_sl(n, s, 1, u, 1);
-    h2 = ddot_sl(n, s, 1, v, 1);
-    h3 = 0.2 * h2;
-    if (h1 < h3) {
-        h4 = (h2 - h3) / (h2 - h1);
-        h1 = h3;
-        dscal_sl(n, h4, u, 1);
-        daxpy_sl(n, 1.0 - h4, v, 1, u, 1);
-    }
-    ldl(n, l, u, +1.0 / h1, v);
-    ldl(n, l, v, -1.0 / h2, u);
+    if (bfgs_hook) bfgs_hook(m, n, la, l, g, a, r, u, v, s);
+    else mpc_slsqp_bfgs_builtin(m, n, la, l, g, a, r, u, v, s);
     goto L130;
 L330:
     S->alpha = alpha; S->f0 = f0; S->gs = gs; S->h1 = h1; S->h2 = h2; S->h3 = h3; S->h4 = h4; S->t = t; S->t0 = t0; S->tol = tol;

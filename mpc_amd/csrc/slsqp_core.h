@@ -28,6 +28,11 @@ typedef void (*mpc_lsq_fn)(int m, int meq, int n, int nl, int la, double *l, dou
 void mpc_slsqp_lsq_builtin(int m, int meq, int n, int nl, int la, double *l, double *g, double *a, double *b, double *xl,
                            double *xu, double *x, double *y, double *w, int *jw, int *mode);
 void mpc_slsqp_set_lsq(mpc_lsq_fn fn);
+/* Likewise for the BFGS update block of the major iteration (l is updated in place; u, v are the body's work
+ * vectors, v holding the previous Lagrangian gradient on entry). */
+typedef void (*mpc_bfgs_fn)(int m, int n, int la, double *l, double *g, double *a, double *r, double *u, double *v, double *s);
+void mpc_slsqp_bfgs_builtin(int m, int n, int la, double *l, double *g, double *a, double *r, double *u, double *v, double *s);
+void mpc_slsqp_set_bfgs(mpc_bfgs_fn fn);
 
 /* Same call with scipy's single workspace array (layout of the Fortran driver SLSQP), for side-by-side tests. */
 void mpc_slsqp_step(int m, int meq, int la, int n, double *x, double *xl, double *xu, double f, double *c, double *g,

@@ -137,10 +137,12 @@ def test_team_parallel_lsq_with_a_team_of_one_keeps_whole_solves_identical(H, N)
 
     want = solve()
     lib.mpc_slsqp_set_lsq(ctypes.cast(lib.mpc_lsq_spmd_serial, ctypes.c_void_p))
+    lib.mpc_slsqp_set_bfgs(ctypes.cast(lib.mpc_bfgs_spmd_serial, ctypes.c_void_p))      # the BFGS / LDL' update likewise
     try:
         got = solve()
     finally:
         lib.mpc_slsqp_set_lsq(None)
+        lib.mpc_slsqp_set_bfgs(None)
     assert len(got[0]) == len(want[0])
     for (xa, ma), (xb, mb) in zip(got[0], want[0]):
         np.testing.assert_array_equal(ma, mb)
