@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MPC_AMD_ABI_VERSION 4
+#define MPC_AMD_ABI_VERSION 5
 #define MPC_MAX_HORIZON 255
 
 typedef enum mpc_status {
@@ -180,6 +180,20 @@ int mpc_prepare_tick(mpc_ctx *ctx, int count, const double *q, const double *dq,
  * scipy's.  All pointers are device pointers.  Needs a context whose horizon matches. */
 int mpc_qp_solve(mpc_ctx *ctx, int count, const double *l, const double *g, const double *c, const double *nz,
                  const double *lo, const double *hi, double *s, double *y, int32_t *mode, void *stream);
+
+/* One major-iteration step of SLSQP solves whose QP side lives on the device (include/mpc_slsqp.h, QP offload),
+ * for the `count` problems listed in index (int32, device, each in [0, rows)): per problem, in this order,
+ *   flags bit 0: reset the LDL' factor of the BFGS matrix to the identity        (the body's "reset BFGS matrix"),
+ *   flags bit 1: BFGS-update it with the new derivatives g, nz, the last step s_in, the multipliers and the
+ *                Lagrangian gradient kept from the previous call                  (the body's block after mode -1),
+ *   solve the QP (as mpc_qp_solve) with the box lo, hi, and keep r and v = g - (dc/dx)^T r for the next update.
+ * Per-problem state, `rows` rows each, owned by the caller and only touched by this call: L [(n+1)n/2 + 1],
+ * R [m + 2n], V [n]; inputs per problem G [n], C [m], NZ [6H + 3H(H+1)] (what mpc_eval / mpc_eval_fd_nz returned at
+ * the problem's current iterate).  Per request (position k in the list): flags, lo, hi, s_in [n] in;
+ * s_out [n], r_out [m] (constraint multipliers), mode out.  Bit-identical to the host core. */
+int mpc_qp_step(mpc_ctx *ctx, int count, int rows, const int32_t *index, const int32_t *flags, const double *lo,
+                const double *hi, const double *s_in, double *L, const double *G, const double *C, const double *NZ, double *R,
+                double *V, double *s_out, double *r_out, int32_t *mode, void *stream);
 
 /* Active-set gather for lock-step solves: scipy's driver evaluates a problem only when its SLSQP core
  * asks (mode 1 / -1, _slsqp_py.py:427-456), so each round of a batched solve touches a changing subset

@@ -55,6 +55,25 @@ const int32_t *mpc_slsqp_iterations(mpc_slsqp_batch *b);
  * problems still running (= *n_want_f + *n_want_g), or a negative code. */
 int mpc_slsqp_advance(mpc_slsqp_batch *b, int32_t *want_f, int32_t *n_want_f, int32_t *want_g, int32_t *n_want_g);
 
+/* QP offload (slsqp_core.h, slsqp_state.offload): the body of every problem stops where it needs the QP
+ * subproblem solved and leaves the LDL' factor of the BFGS matrix, its updates and the QP to the caller
+ * (mpc_qp_step of libmpc_amd keeps them on the GPU).  Switch on BEFORE mpc_slsqp_begin.  Then use
+ * mpc_slsqp_advance_qp: want_q lists the problems waiting for a QP; for each of them the caller reads
+ * lo / hi (rows [n+1], first n entries: the box xl - x, xu - x around the iterate), s (row [n+1], first n: the
+ * last step, input of the BFGS update) and qp_flags (bit 0: reset the factor to the identity first, bit 1: update it
+ * with the new derivatives first), and writes the new step into s, the m constraint multipliers into r
+ * (rows [m + 2n + 2]) and the QP's mode into qp_mode.  In this mode the host needs f, c (mode 1) and grad f
+ * (mode -1) only: dc/dx stays with the caller. */
+int mpc_slsqp_set_offload(mpc_slsqp_batch *b, int on);
+int mpc_slsqp_advance_qp(mpc_slsqp_batch *b, int32_t *want_f, int32_t *n_want_f, int32_t *want_g, int32_t *n_want_g,
+                         int32_t *want_q, int32_t *n_want_q);
+double *mpc_slsqp_lo(mpc_slsqp_batch *b);
+double *mpc_slsqp_hi(mpc_slsqp_batch *b);
+double *mpc_slsqp_s(mpc_slsqp_batch *b);
+double *mpc_slsqp_r(mpc_slsqp_batch *b);
+int32_t *mpc_slsqp_qp_mode(mpc_slsqp_batch *b);
+const int32_t *mpc_slsqp_qp_flags(mpc_slsqp_batch *b);
+
 /* Seconds spent inside the core by the busiest thread / wall seconds of all rounds since mpc_slsqp_begin. */
 double mpc_slsqp_core_seconds(const mpc_slsqp_batch *b);
 

@@ -11,11 +11,11 @@ LIB_PATH = os.environ.get("MPC_AMD_LIB") or os.path.join(_HERE, "libmpc_amd.so")
 MPC_OK = 0
 ALGO_AUTO, ALGO_ROLLOUT, ALGO_PREFIX = 0, 1, 2
 MAX_HORIZON = 255
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 EXPORTS = (
     "mpc_abi_version", "mpc_ctx_create", "mpc_ctx_destroy", "mpc_set_params", "mpc_eval", "mpc_eval_fd",
-    "mpc_jacobian", "mpc_fk", "mpc_predict_base_dynamic", "mpc_prepare_tick", "mpc_qp_solve", "mpc_gather_scenarios", "mpc_jacobian_nz_count", "mpc_eval_fd_nz",
+    "mpc_jacobian", "mpc_fk", "mpc_predict_base_dynamic", "mpc_prepare_tick", "mpc_qp_solve", "mpc_qp_step", "mpc_gather_scenarios", "mpc_jacobian_nz_count", "mpc_eval_fd_nz",
     "mpc_expand_jacobian", "mpc_last_error",
 )
 
@@ -87,6 +87,8 @@ def load():
     L.mpc_prepare_tick.argtypes = [vp, ip, vp, vp, vp, vp, dp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     L.mpc_qp_solve.restype = ip
     L.mpc_qp_solve.argtypes = [vp, ip, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    L.mpc_qp_step.restype = ip
+    L.mpc_qp_step.argtypes = [vp, ip, ip] + [vp] * 15
     L.mpc_jacobian_nz_count.restype = ip
     L.mpc_jacobian_nz_count.argtypes = [ip]
     L.mpc_eval_fd_nz.restype = ip

@@ -329,6 +329,31 @@ int mpc_prepare_tick(mpc_ctx *ctx, int count, const double *q, const double *dq,
     return MPC_OK;
 }
 
+namespace {
+
+int qp_workspace(mpc_ctx *ctx)
+{
+    if (ctx->d_qp_work) return MPC_OK;
+    // up to four resident workgroups per CU; each owns ~1.1 MB of workspace at H = 20
+    hipDeviceProp_t prop;
+    MPC_HIP(ctx, hipGetDeviceProperties(&prop, ctx->device));
+    int teams = 4 * prop.multiProcessorCount;
+    if (teams > ctx->max_scenarios) teams = ctx->max_scenarios;
+    const size_t wd = mpck::qp_work_doubles(ctx->horizon), wi = mpck::qp_work_ints(ctx->horizon);
+    while (teams > 1 && (size_t)teams * wd * sizeof(double) > (size_t(4) << 30)) teams /= 2;
+    MPC_HIP(ctx, hipMalloc(&ctx->d_qp_work, (size_t)teams * wd * sizeof(double)));
+    hipError_t e = hipMalloc(&ctx->d_qp_iwork, (size_t)teams * wi * sizeof(int));
+    if (e != hipSuccess) {
+        (void)hipFree(ctx->d_qp_work);
+        ctx->d_qp_work = nullptr;
+        return hip_fail(ctx, e, "hipMalloc(qp iwork)");
+    }
+    ctx->qp_teams = teams;
+    return MPC_OK;
+}
+
+}  // namespace
+
 int mpc_qp_solve(mpc_ctx *ctx, int count, const double *l, const double *g, const double *c, const double *nz,
                  const double *lo, const double *hi, double *s, double *y, int32_t *mode, void *stream)
 {
@@ -340,26 +365,32 @@ int mpc_qp_solve(mpc_ctx *ctx, int count, const double *l, const double *g, cons
     if (!l || !g || !c || !nz || !lo || !hi || !s || !y || !mode)
         return fail(ctx, MPC_ERR_INVALID_ARG, "l/g/c/nz/lo/hi/s/y/mode must be non-NULL");
     MPC_HIP(ctx, hipSetDevice(ctx->device));
-    if (!ctx->d_qp_work) {
-        // up to four resident workgroups per CU; each owns ~1.1 MB of workspace at H = 20
-        hipDeviceProp_t prop;
-        MPC_HIP(ctx, hipGetDeviceProperties(&prop, ctx->device));
-        int teams = 4 * prop.multiProcessorCount;
-        if (teams > ctx->max_scenarios) teams = ctx->max_scenarios;
-        const size_t wd = mpck::qp_work_doubles(ctx->horizon), wi = mpck::qp_work_ints(ctx->horizon);
-        while (teams > 1 && (size_t)teams * wd * sizeof(double) > (size_t(4) << 30)) teams /= 2;
-        MPC_HIP(ctx, hipMalloc(&ctx->d_qp_work, (size_t)teams * wd * sizeof(double)));
-        hipError_t e = hipMalloc(&ctx->d_qp_iwork, (size_t)teams * wi * sizeof(int));
-        if (e != hipSuccess) {
-            (void)hipFree(ctx->d_qp_work);
-            ctx->d_qp_work = nullptr;
-            return hip_fail(ctx, e, "hipMalloc(qp iwork)");
-        }
-        ctx->qp_teams = teams;
-    }
+    rc = qp_workspace(ctx);
+    if (rc) return rc;
     const int teams = count < ctx->qp_teams ? count : ctx->qp_teams;
     MPC_HIP(ctx, mpck::launch_qp(ctx->horizon, count, teams, l, g, c, nz, lo, hi, s, y, mode, ctx->d_qp_work, ctx->d_qp_iwork,
                                  static_cast<hipStream_t>(stream)));
+    return MPC_OK;
+}
+
+int mpc_qp_step(mpc_ctx *ctx, int count, int rows, const int32_t *index, const int32_t *flags, const double *lo,
+                const double *hi, const double *s_in, double *L, const double *G, const double *C, const double *NZ, double *R,
+                double *V, double *s_out, double *r_out, int32_t *mode, void *stream)
+{
+    int rc = check_ready(ctx);
+    if (rc) return rc;
+    if (count < 0 || count > ctx->max_scenarios || rows < count)
+        return fail(ctx, MPC_ERR_INVALID_ARG, "count %d outside [0, %d] or more requests than rows (%d)", count,
+                    ctx->max_scenarios, rows);
+    if (count == 0) return MPC_OK;
+    if (!index || !flags || !lo || !hi || !s_in || !L || !G || !C || !NZ || !R || !V || !s_out || !r_out || !mode)
+        return fail(ctx, MPC_ERR_INVALID_ARG, "every array of mpc_qp_step must be non-NULL");
+    MPC_HIP(ctx, hipSetDevice(ctx->device));
+    rc = qp_workspace(ctx);
+    if (rc) return rc;
+    const int teams = count < ctx->qp_teams ? count : ctx->qp_teams;
+    MPC_HIP(ctx, mpck::launch_qp_step(ctx->horizon, count, teams, index, flags, lo, hi, s_in, L, G, C, NZ, R, V, s_out, r_out,
+                                      mode, ctx->d_qp_work, ctx->d_qp_iwork, static_cast<hipStream_t>(stream)));
     return MPC_OK;
 }
 

@@ -61,6 +61,11 @@ hipError_t launch_qp(int H, int count, int teams, const double *l, const double 
                      const double *lo, const double *hi, double *s, double *y, int32_t *mode, double *work, int *iwork,
                      hipStream_t stream);
 
+hipError_t launch_qp_step(int H, int count, int teams, const int32_t *index, const int32_t *flags, const double *lo,
+                          const double *hi, const double *s_in, double *L, const double *G, const double *C, const double *NZ,
+                          double *R, double *V, double *s_out, double *r_out, int32_t *mode, double *work, int *iwork,
+                          hipStream_t stream);
+
 // dst row i = src row index[i] for every scenario array (NaN rows for an index outside [0, src.count))
 hipError_t launch_gather_scenarios(int H, const mpc_scenarios &src, const int32_t *index, int count,
                                    const mpc_scenarios &dst, hipStream_t stream);

@@ -11,7 +11,8 @@ struct mpc_slsqp_batch {
     size_t lw, ldl_len, r_len;
     /* per problem */
     double *x, *f, *c, *g, *nz, *mu, *l, *x0, *r, *s, *u, *v, *acc;
-    int32_t *iter, *mode;
+    int32_t *iter, *mode, *qpmode, *qpflags;
+    int offload;
     unsigned char *done;
     slsqp_state *st;
     /* shared */
@@ -31,7 +32,7 @@ void mpc_slsqp_destroy(mpc_slsqp_batch *b)
 {
     if (!b) return;
     free(b->x); free(b->f); free(b->c); free(b->g); free(b->nz); free(b->mu); free(b->l); free(b->x0); free(b->r);
-    free(b->s); free(b->u); free(b->v); free(b->acc); free(b->iter); free(b->mode); free(b->done); free(b->st);
+    free(b->s); free(b->u); free(b->v); free(b->acc); free(b->iter); free(b->mode); free(b->qpmode); free(b->qpflags); free(b->done); free(b->st);
     free(b->lb); free(b->ub); free(b->scatter); free(b->wscr); free(b->ascr); free(b->tsec); free(b->jwscr);
     free(b);
 }
@@ -59,12 +60,13 @@ int mpc_slsqp_create(int horizon, int capacity, int threads, mpc_slsqp_batch **o
     b->nz = zalloc(N * b->nzc, 8); b->mu = zalloc(N * m, 8); b->l = zalloc(N * b->ldl_len, 8); b->x0 = zalloc(N * n, 8);
     b->r = zalloc(N * b->r_len, 8); b->s = zalloc(N * n1, 8); b->u = zalloc(N * n1, 8); b->v = zalloc(N * n1, 8);
     b->acc = zalloc(N, 8); b->iter = zalloc(N, 4); b->mode = zalloc(N, 4); b->done = zalloc(N, 1);
+    b->qpmode = zalloc(N, 4); b->qpflags = zalloc(N, 4);
     b->st = zalloc(N, sizeof(slsqp_state));
     b->lb = zalloc(n, 8); b->ub = zalloc(n, 8); b->scatter = zalloc(b->nzc, 4);
     b->wscr = zalloc(T * b->lw, 8); b->ascr = zalloc(T * (size_t)n1 * m, 8); b->tsec = zalloc(T, 8);
     b->jwscr = zalloc(T * (size_t)b->ljw, sizeof(int));
     if (!b->x || !b->f || !b->c || !b->g || !b->nz || !b->mu || !b->l || !b->x0 || !b->r || !b->s || !b->u || !b->v ||
-        !b->acc || !b->iter || !b->mode || !b->done || !b->st || !b->lb || !b->ub || !b->scatter || !b->wscr || !b->ascr ||
+        !b->acc || !b->iter || !b->mode || !b->qpmode || !b->qpflags || !b->done || !b->st || !b->lb || !b->ub || !b->scatter || !b->wscr || !b->ascr ||
         !b->tsec || !b->jwscr) {
         mpc_slsqp_destroy(b);
         return -2;
@@ -103,6 +105,9 @@ int mpc_slsqp_begin(mpc_slsqp_batch *b, int count, const double *x0, const doubl
         b->mode[p] = 0;
         b->done[p] = 0;
         memset(&b->st[p], 0, sizeof(slsqp_state));
+        b->st[p].offload = b->offload;
+        b->qpmode[p] = 0;
+        b->qpflags[p] = 0;
     }
     for (int t = 0; t < b->threads; ++t) b->tsec[t] = 0.0;
     b->wall = 0.0;
@@ -117,6 +122,19 @@ double *mpc_slsqp_nz(mpc_slsqp_batch *b) { return b->nz; }
 const int32_t *mpc_slsqp_mode(mpc_slsqp_batch *b) { return b->mode; }
 const int32_t *mpc_slsqp_iterations(mpc_slsqp_batch *b) { return b->iter; }
 
+int mpc_slsqp_set_offload(mpc_slsqp_batch *b, int on)
+{
+    if (!b) return -1;
+    b->offload = on ? 1 : 0;
+    return 0;
+}
+double *mpc_slsqp_lo(mpc_slsqp_batch *b) { return b->u; }
+double *mpc_slsqp_hi(mpc_slsqp_batch *b) { return b->v; }
+double *mpc_slsqp_s(mpc_slsqp_batch *b) { return b->s; }
+double *mpc_slsqp_r(mpc_slsqp_batch *b) { return b->r; }
+int32_t *mpc_slsqp_qp_mode(mpc_slsqp_batch *b) { return b->qpmode; }
+const int32_t *mpc_slsqp_qp_flags(mpc_slsqp_batch *b) { return b->qpflags; }
+
 double mpc_slsqp_core_seconds(const mpc_slsqp_batch *b)
 {
     double mx = 0.0;
@@ -124,9 +142,11 @@ double mpc_slsqp_core_seconds(const mpc_slsqp_batch *b)
     return mx;
 }
 
-int mpc_slsqp_advance(mpc_slsqp_batch *b, int32_t *want_f, int32_t *n_want_f, int32_t *want_g, int32_t *n_want_g)
+int mpc_slsqp_advance_qp(mpc_slsqp_batch *b, int32_t *want_f, int32_t *n_want_f, int32_t *want_g, int32_t *n_want_g,
+                         int32_t *want_q, int32_t *n_want_q)
 {
     if (!b || !want_f || !n_want_f || !want_g || !n_want_g) return -1;
+    if (b->offload && (!want_q || !n_want_q)) return -1;
     const int n = b->n, m = b->m, n1 = b->n1, nzc = b->nzc;
     const double t_round = omp_get_wtime();
 #pragma omp parallel for schedule(dynamic, 1) num_threads(b->threads)
@@ -136,7 +156,10 @@ int mpc_slsqp_advance(mpc_slsqp_batch *b, int32_t *want_f, int32_t *n_want_f, in
         const double t0 = omp_get_wtime();
         double *a = b->ascr + (size_t)tid * n1 * m;
         double *g = b->g + (size_t)p * n1;
-        if (b->mode[p] != 1) {
+        if (b->offload) {
+            if (b->mode[p] == MPC_SLSQP_MODE_QP) b->st[p].qp_mode = b->qpmode[p];
+            if (b->mode[p] != 1) g[n] = 0.0;
+        } else if (b->mode[p] != 1) {
             /* fresh derivatives: the dense a(m, n+1) of this call, zero except the structured entries.  A call
              * that follows a line-search evaluation (mode 1) does not read a. */
             memset(a, 0, sizeof(double) * (size_t)n1 * m);
@@ -151,17 +174,26 @@ int mpc_slsqp_advance(mpc_slsqp_batch *b, int32_t *want_f, int32_t *n_want_f, in
                    b->jwscr + (size_t)tid * b->ljw, &b->st[p]);
         b->mode[p] = mode;
         b->iter[p] = iter;
-        if (mode != 1 && mode != -1) b->done[p] = 1;
+        b->qpflags[p] = (b->st[p].qp_reset ? 1 : 0) | (b->st[p].qp_bfgs ? 2 : 0);
+        if (mode != 1 && mode != -1 && mode != MPC_SLSQP_MODE_QP) b->done[p] = 1;
         b->tsec[tid] += omp_get_wtime() - t0;
     }
-    int nf = 0, ng = 0;
+    int nf = 0, ng = 0, nq = 0;
     for (int p = 0; p < b->count; ++p) {
         if (b->done[p]) continue;
         if (b->mode[p] == 1) want_f[nf++] = p;
-        else want_g[ng++] = p;
+        else if (b->mode[p] == -1) want_g[ng++] = p;
+        else if (want_q) want_q[nq++] = p;
     }
     *n_want_f = nf;
     *n_want_g = ng;
+    if (n_want_q) *n_want_q = nq;
     b->wall += omp_get_wtime() - t_round;
-    return nf + ng;
+    return nf + ng + nq;
+}
+
+int mpc_slsqp_advance(mpc_slsqp_batch *b, int32_t *want_f, int32_t *n_want_f, int32_t *want_g, int32_t *n_want_g)
+{
+    if (!b || b->offload) return -1;
+    return mpc_slsqp_advance_qp(b, want_f, n_want_f, want_g, n_want_g, 0, 0);
 }

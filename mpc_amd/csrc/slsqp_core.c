@@ -642,6 +642,7 @@ void mpc_slsqpb(int m, int meq, int la, int n, double *x, double *xl, double *xu
            tol = S->tol;
     int iexact = S->iexact, incons = S->incons, ireset = S->ireset, itermx = S->itermx, line = S->line, n1 = S->n1,
         n2 = S->n2, n3 = S->n3;
+    if (*mode == MPC_SLSQP_MODE_QP) goto L135;
     if (*mode < 0) goto L260;
     if (*mode > 0) goto L220;
     itermx = *iter;
@@ -658,9 +659,12 @@ void mpc_slsqpb(int m, int meq, int la, int n, double *x, double *xl, double *xu
 L110:
     ireset = ireset + 1;
     if (ireset > 5) goto L255;
-    for (i = 0; i < n2; ++i) l[i] = 0.0;
-    j = 1;
-    for (i = 1; i <= n; ++i) { l[j - 1] = 1.0; j = j + n1 - i; }
+    if (S->offload) S->qp_reset = 1;
+    else {
+        for (i = 0; i < n2; ++i) l[i] = 0.0;
+        j = 1;
+        for (i = 1; i <= n; ++i) { l[j - 1] = 1.0; j = j + n1 - i; }
+    }
 L130:
     *iter = *iter + 1;
     *mode = 9;
@@ -670,7 +674,18 @@ L130:
     daxpy_sl(n, -1.0, x, 1, u, 1);
     daxpy_sl(n, -1.0, x, 1, v, 1);
     h4 = 1.0;
+    if (S->offload) {
+        *mode = MPC_SLSQP_MODE_QP;          /* the caller solves the QP: box in u, v */
+        goto L330;
+    }
     lsq_dispatch(m, meq, n, n3, la, l, g, a, c, u, v, s, r, w, iw, mode);
+    goto L136;
+L135:
+    *mode = S->qp_mode;                     /* s and r were written by the caller */
+    S->qp_reset = 0;
+    S->qp_bfgs = 0;
+    if (*mode == 4 || (*mode == 6 && n == meq)) { *mode = MPC_SLSQP_MODE_NEEDS_HOST; goto L330; }
+L136:
     badlin = 0;
     if (*mode == 6 && n == meq) *mode = 4;
     if (*mode == 4) {
@@ -694,7 +709,8 @@ L130:
             goto L150;
         } else if (*mode != 1) goto L330;
     } else if (*mode != 1) goto L330;
-    for (i = 1; i <= n; ++i) v[i - 1] = g[i - 1] - ddot_sl(m, &A(1, i), 1, r, 1);
+    if (!S->offload)                        /* offloaded: kept where l lives, it only feeds the BFGS update */
+        for (i = 1; i <= n; ++i) v[i - 1] = g[i - 1] - ddot_sl(m, &A(1, i), 1, r, 1);
     f0 = f;
     dcopy_(n, x, 1, x0, 1);
     gs = ddot_sl(n, g, 1, s, 1);
@@ -760,6 +776,7 @@ L255:
     else *mode = 8;
     goto L330;
 L260:
+    if (S->offload) { S->qp_bfgs = 1; goto L130; }
     if (bfgs_hook) bfgs_hook(m, n, la, l, g, a, r, u, v, s);
     else mpc_slsqp_bfgs_builtin(m, n, la, l, g, a, r, u, v, s);
     goto L130;

@@ -10,7 +10,18 @@ extern "C" {
 typedef struct slsqp_state {
     double alpha, f0, gs, h1, h2, h3, h4, t, t0, tol;
     int iexact, incons, ireset, itermx, line, n1, n2, n3;
+    /* QP offload (all zero = everything on the host).  With `offload` set the body never touches l or a: where
+     * it would reset l it sets qp_reset, where it would update l (BFGS) it sets qp_bfgs, and where it would solve
+     * the QP it returns MPC_SLSQP_MODE_QP with u = xl - x and v = xu - x in place.  The caller resets / updates l,
+     * solves the QP (mpc_qp_step in include/mpc_amd.h does all three on the device), writes the step into s, the
+     * constraint multipliers into r, the QP's mode into qp_mode, and calls again with mode = MPC_SLSQP_MODE_QP. */
+    int offload, qp_mode, qp_reset, qp_bfgs;
 } slsqp_state;
+
+#define MPC_SLSQP_MODE_QP 20
+/* exit mode of an offloaded solve whose linearisation was inconsistent (Kraft's augmented problem needs l on the
+ * host): the caller solves that problem again with the host-only driver */
+#define MPC_SLSQP_MODE_NEEDS_HOST 104
 
 /* Body of the method with its persistent vectors passed one by one: r [m + 2n + 2] multipliers,
  * l [(n+1)n/2 + 1] LDL' factor of the BFGS matrix, x0 [n], mu [m], s / u / v [n+1], and per-call

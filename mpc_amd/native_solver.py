@@ -51,6 +51,18 @@ def load():
         fn.argtypes = [vp]
     L.mpc_slsqp_advance.restype = ip
     L.mpc_slsqp_advance.argtypes = [vp, i32p, i32p, i32p, i32p]
+    L.mpc_slsqp_set_offload.restype = ip
+    L.mpc_slsqp_set_offload.argtypes = [vp, ip]
+    L.mpc_slsqp_advance_qp.restype = ip
+    L.mpc_slsqp_advance_qp.argtypes = [vp, i32p, i32p, i32p, i32p, i32p, i32p]
+    for name in ("lo", "hi", "s", "r"):
+        fn = getattr(L, f"mpc_slsqp_{name}")
+        fn.restype = dp
+        fn.argtypes = [vp]
+    for name in ("qp_mode", "qp_flags"):
+        fn = getattr(L, f"mpc_slsqp_{name}")
+        fn.restype = i32p
+        fn.argtypes = [vp]
     L.mpc_slsqp_core_seconds.restype = C.c_double
     L.mpc_slsqp_core_seconds.argtypes = [vp]
     if L.mpc_slsqp_abi_version() != ABI_VERSION:
@@ -62,7 +74,7 @@ def load():
 class NativeBatch:
     """ctypes view of one ``mpc_slsqp_batch``: the rows as numpy arrays over the library's memory."""
 
-    def __init__(self, horizon: int, capacity: int, threads: int = 0):
+    def __init__(self, horizon: int, capacity: int, threads: int = 0, offload_qp: bool = False):
         self._lib = load()
         self._b = C.c_void_p()
         rc = self._lib.mpc_slsqp_create(horizon, capacity, threads, C.byref(self._b))
@@ -83,6 +95,16 @@ class NativeBatch:
         self.iterations = view(L.mpc_slsqp_iterations, (capacity,))
         self._wf = np.zeros(capacity, dtype=np.int32)
         self._wg = np.zeros(capacity, dtype=np.int32)
+        self._wq = np.zeros(capacity, dtype=np.int32)
+        self.offload_qp = bool(offload_qp)
+        if self.offload_qp:
+            self._lib.mpc_slsqp_set_offload(self._b, 1)
+            self.LO = view(L.mpc_slsqp_lo, (capacity, self.n + 1))
+            self.HI = view(L.mpc_slsqp_hi, (capacity, self.n + 1))
+            self.S = view(L.mpc_slsqp_s, (capacity, self.n + 1))
+            self.R = view(L.mpc_slsqp_r, (capacity, self.m + 2 * self.n + 2))
+            self.QPMODE = view(L.mpc_slsqp_qp_mode, (capacity,))
+            self.QPFLAGS = view(L.mpc_slsqp_qp_flags, (capacity,))
 
     def begin(self, x0: np.ndarray, lb: np.ndarray, ub: np.ndarray, acc: float, maxiter: int):
         x0 = np.ascontiguousarray(x0, dtype=np.float64)
@@ -103,13 +125,23 @@ class NativeBatch:
             raise RuntimeError(f"mpc_slsqp_advance failed ({rc})")
         return self._wf[:nf.value], self._wg[:ng.value]
 
+    def advance_qp(self):
+        """One round with the QP offloaded: (want f and c, want grad f and dc/dx, want their QP solved)."""
+        nf, ng, nq = C.c_int32(0), C.c_int32(0), C.c_int32(0)
+        i32 = lambda a: a.ctypes.data_as(C.POINTER(C.c_int32))
+        rc = self._lib.mpc_slsqp_advance_qp(self._b, i32(self._wf), C.byref(nf), i32(self._wg), C.byref(ng), i32(self._wq),
+                                            C.byref(nq))
+        if rc < 0:
+            raise RuntimeError(f"mpc_slsqp_advance_qp failed ({rc})")
+        return self._wf[:nf.value], self._wg[:ng.value], self._wq[:nq.value]
+
     @property
     def core_seconds(self) -> float:
         return float(self._lib.mpc_slsqp_core_seconds(self._b))
 
     def close(self):
         if getattr(self, "_b", None) is not None and self._b.value:
-            for name in ("X", "F", "Cc", "G", "NZ", "mode", "iterations"):
+            for name in ("X", "F", "Cc", "G", "NZ", "mode", "iterations", "LO", "HI", "S", "R", "QPMODE", "QPFLAGS"):
                 setattr(self, name, None)
             self._lib.mpc_slsqp_destroy(self._b)
             self._b = C.c_void_p()
@@ -247,6 +279,154 @@ class NativeBatchedSLSQP:
         self._helper.shutdown(wait=True)
         for b in self.batches:
             b.close()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+
+MODE_NEEDS_HOST = 104      # slsqp_core.h: MPC_SLSQP_MODE_NEEDS_HOST
+
+
+class DeviceQpSLSQP:
+    """Batched SLSQP with the quadratic subproblems on the GPU.
+
+    The O(n^2)..O(n^3) linear algebra of every major iteration - the BFGS update of the LDL' factor and the QP
+    (``mpc_qp_step``: one workgroup per problem, arithmetic identical to the host core) - runs on the device,
+    where the factor, the derivatives and the multipliers of every problem stay resident; the host threads
+    keep the O(n + m) logic of the method (merit function, line search, convergence tests).  Per QP only the box,
+    the last step and the new step with its multipliers cross PCIe.  Results equal the host drivers' bit for bit.
+    A problem whose linearisation turns out inconsistent (Kraft's augmented problem) is solved again by the
+    host-only driver."""
+
+    def __init__(self, ctx: MpcContext, threads: int = 0, capacity: int = None):
+        if not ctx.nz_supported():
+            raise ValueError("the driver takes dc/dx in its structured form: the context needs MPC_ALGO_PREFIX")
+        self.ctx = ctx
+        p = ctx.params
+        self.cap = cap = int(capacity or ctx.max_scenarios)
+        self.threads = threads
+        self.batch = NativeBatch(p.horizon, cap, threads, offload_qp=True)
+        self.lb = np.array([b[0] for b in p.bounds()])
+        self.ub = np.array([b[1] for b in p.bounds()])
+        dev, n, m = ctx.device, p.n, p.m
+        z = lambda *shape: torch.empty(shape, dtype=torch.float64, device=dev)
+        self._x_dev = z(cap, n)
+        self._out = EvalResult(z(cap), z(cap, n), z(cap, m), None, z(cap, ctx.nz_count))
+        self._sub = {False: ScenarioBatch.empty(dev, cap, p.horizon, False), True: ScenarioBatch.empty(dev, cap, p.horizon, True)}
+        # per-problem state that never leaves the device
+        self._L = z(cap, (n + 1) * n // 2 + 1)
+        self._G, self._C, self._NZ = z(cap, n), z(cap, m), z(cap, ctx.nz_count)
+        self._R, self._V = z(cap, m + 2 * n), z(cap, n)
+        self._host_fallback = None
+
+    def _eval(self, sc, idx, need_grad):
+        ctx, b, o = self.ctx, self.batch, self._out
+        K = len(idx)
+        self._x_dev[:K].copy_(torch.from_numpy(np.clip(b.X[idx], self.lb, self.ub)))       # _clip_x_for_func
+        idx_dev = torch.from_numpy(idx.astype(np.int32)).to(ctx.device)
+        sub = ctx.gather(sc, idx_dev, self._sub[sc.u_prev is not None])
+        rows = idx_dev.long()
+        if need_grad:
+            ctx.eval_fd_nz(sub, self._x_dev[:K], want_con=False,
+                           out=EvalResult(o.cost[:K], o.grad[:K], None, None, o.con_jac_nz[:K]))
+            self._G.index_copy_(0, rows, o.grad[:K])
+            self._NZ.index_copy_(0, rows, o.con_jac_nz[:K])
+            b.G[idx, :b.n] = o.grad[:K].cpu().numpy()
+        else:
+            ctx.eval(sub, self._x_dev[:K], out=EvalResult(o.cost[:K], None, o.con[:K], None))
+            self._C.index_copy_(0, rows, o.con[:K])
+            b.F[idx] = o.cost[:K].cpu().numpy()
+            b.Cc[idx] = o.con[:K].cpu().numpy()
+
+    def _qp(self, idx):
+        ctx, b = self.ctx, self.batch
+        n, m = b.n, b.m
+        K = len(idx)
+        dev = ctx.device
+        up = lambda a, dt=torch.float64: torch.as_tensor(np.ascontiguousarray(a), dtype=dt).to(dev)
+        lo, hi, s_in = up(b.LO[idx, :n]), up(b.HI[idx, :n]), up(b.S[idx, :n])
+        index, flags = up(idx, torch.int32), up(b.QPFLAGS[idx], torch.int32)
+        s_out = torch.empty((K, n), dtype=torch.float64, device=dev)
+        r_out = torch.empty((K, m), dtype=torch.float64, device=dev)
+        mode = torch.zeros(K, dtype=torch.int32, device=dev)
+        from . import _ffi
+        _ffi.check(ctx._ctx, ctx._lib.mpc_qp_step(
+            ctx._ctx, K, self.cap, index.data_ptr(), flags.data_ptr(), lo.data_ptr(), hi.data_ptr(), s_in.data_ptr(),
+            self._L.data_ptr(), self._G.data_ptr(), self._C.data_ptr(), self._NZ.data_ptr(), self._R.data_ptr(),
+            self._V.data_ptr(), s_out.data_ptr(), r_out.data_ptr(), mode.data_ptr(), ctx._stream()))
+        md = mode.cpu().numpy()
+        ok = md == 1
+        b.S[idx[ok], :n] = s_out.cpu().numpy()[ok]
+        b.R[idx[ok], :m] = r_out.cpu().numpy()[ok]
+        b.QPMODE[idx] = md
+
+    def solve(self, sc: ScenarioBatch, x0: np.ndarray) -> BatchSolveResult:
+        ctx, b = self.ctx, self.batch
+        p = ctx.params
+        N, n = sc.count, p.n
+        if N > self.cap:
+            raise ValueError(f"{N} scenarios > capacity {self.cap}")
+        if N == 0:
+            return BatchSolveResult(np.zeros((0, n)), np.zeros(0), np.zeros(0, int), np.zeros(0, int), 0, 0, 0)
+        x0 = np.asarray(x0, dtype=np.float64).reshape(N, n)
+        b.begin(x0, self.lb, self.ub, p.ftol, p.maxiter)
+        t_serve = 0.0
+        t0 = time.perf_counter()
+        o = self._out
+        self._x_dev[:N].copy_(torch.from_numpy(b.X[:N]))
+        ctx.eval_fd_nz(sc, self._x_dev[:N], out=EvalResult(o.cost[:N], o.grad[:N], o.con[:N], None, o.con_jac_nz[:N]))
+        self._G[:N].copy_(o.grad[:N])
+        self._C[:N].copy_(o.con[:N])
+        self._NZ[:N].copy_(o.con_jac_nz[:N])
+        b.F[:N] = o.cost[:N].cpu().numpy()
+        b.Cc[:N] = o.con[:N].cpu().numpy()
+        b.G[:N, :n] = o.grad[:N].cpu().numpy()
+        t_serve += time.perf_counter() - t0
+        n_eval, n_eval_fd, n_qp, rounds = 0, N, 0, 0
+        t_qp = 0.0
+        while True:
+            want_f, want_g, want_q = (w.copy() for w in b.advance_qp())
+            rounds += 1
+            if len(want_f) + len(want_g) + len(want_q) == 0:
+                break
+            t0 = time.perf_counter()
+            if len(want_f):
+                self._eval(sc, want_f, False)
+                n_eval += len(want_f)
+            if len(want_g):
+                self._eval(sc, want_g, True)
+                n_eval_fd += len(want_g)
+            t1 = time.perf_counter()
+            if len(want_q):
+                self._qp(want_q)
+                n_qp += len(want_q)
+            t2 = time.perf_counter()
+            t_serve += t1 - t0
+            t_qp += t2 - t1
+        x, fun = b.X[:N].copy(), b.F[:N].copy()
+        nit, status = b.iterations[:N].astype(int), b.mode[:N].astype(int)
+        redo = np.nonzero(status == MODE_NEEDS_HOST)[0]
+        if len(redo):                       # inconsistent linearisation somewhere along the way: host-only solve
+            if self._host_fallback is None:
+                self._host_fallback = NativeBatchedSLSQP(ctx, threads=self.threads, capacity=self.cap, groups=1)
+            sub = ctx.gather(sc, torch.from_numpy(redo.astype(np.int32)).to(ctx.device),
+                             ScenarioBatch.empty(ctx.device, len(redo), p.horizon, sc.u_prev is not None))
+            r2 = self._host_fallback.solve(sub, x0[redo])
+            x[redo], fun[redo], nit[redo], status[redo] = r2.x, r2.fun, r2.nit, r2.status
+            n_eval += r2.n_eval
+            n_eval_fd += r2.n_eval_fd
+        res = BatchSolveResult(x=x, fun=fun, nit=nit, status=status, rounds=rounds, n_eval=n_eval, n_eval_fd=n_eval_fd,
+                               t_core=b.core_seconds, t_serve=t_serve)
+        res.n_qp, res.t_qp, res.n_host_fallback = n_qp, t_qp, len(redo)
+        return res
+
+    def close(self):
+        self.batch.close()
+        if self._host_fallback is not None:
+            self._host_fallback.close()
 
     def __enter__(self):
         return self

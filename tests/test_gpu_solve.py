@@ -421,3 +421,30 @@ def test_qp_subproblem_on_the_device_is_bit_identical_to_the_host_core(H, N):
     np.testing.assert_array_equal(mode.cpu().numpy(), np.array([r[8] for r in rec]))
     np.testing.assert_array_equal(s.cpu().numpy(), np.stack([r[6] for r in rec]))
     np.testing.assert_array_equal(y.cpu().numpy()[:, :m], np.stack([r[7] for r in rec]))
+
+
+def test_device_qp_driver_equals_host_driver():
+    """SLSQP with the BFGS update and the QP of every major iteration on the GPU (mpc_qp_step) and the scalar logic
+    on host threads: iterates, exit modes, iteration and evaluation counts identical to the host-only driver."""
+    from helpers import host_scenarios
+    from mpc_amd.batch import MpcContext
+    from mpc_amd.native_solver import DeviceQpSLSQP, NativeBatchedSLSQP
+    from mpc_amd.scenarios import to_device
+
+    for H, count, prev in ((1, 9, False), (3, 40, True), (20, 24, False)):
+        mp = MpcParams.reference_yaml_defaults(horizon=H)
+        ctx = MpcContext(mp, 64, 0)
+        _, hs = host_scenarios(mp, count, motion="angular", cfg_id=19, with_prev=prev)
+        sc, _ = to_device(ctx, hs)
+        with NativeBatchedSLSQP(ctx, threads=3) as host:
+            one = host.solve(sc, hs.x)
+        with DeviceQpSLSQP(ctx, threads=3) as dev:
+            two = dev.solve(sc, hs.x)
+            again = dev.solve(sc.slice(0, 5), hs.x[:5])
+        np.testing.assert_array_equal(two.status, one.status)
+        np.testing.assert_array_equal(two.nit, one.nit)
+        np.testing.assert_array_equal(two.x, one.x)
+        np.testing.assert_array_equal(two.fun, one.fun)
+        assert (two.n_eval, two.n_eval_fd) == (one.n_eval, one.n_eval_fd)
+        assert two.n_qp >= int(one.nit.sum())
+        np.testing.assert_array_equal(again.x, one.x[:5])
