@@ -14,18 +14,34 @@ struct HipTeam {
     __device__ void sync() const { __syncthreads(); }
 };
 
+extern __shared__ double qp_lds[];
+
+// The team's workspace: the two matrices in its slice of global memory, the packed triangle and the vectors in
+// LDS when the launch gave it room for them (lds != 0), else in the same slice.
+__device__ lsqspmd::Work team_work(double *work, int *iwork, size_t wd, size_t wi, int n, int m, int lds)
+{
+    double *big = work + (size_t)blockIdx.x * wd;
+    if (!lds) return lsqspmd::carve(big, big + lsqspmd::big_doubles(n, m), iwork + (size_t)blockIdx.x * wi, n, m, (int)blockDim.x);
+    double *small = qp_lds;
+    return lsqspmd::carve(big, small, reinterpret_cast<int *>(small + lsqspmd::small_doubles(n, m, (int)blockDim.x)), n, m,
+                          (int)blockDim.x);
+}
+
 __global__ void __launch_bounds__(mpck::kQpThreads)
 qp_kernel(int H, int count, const double *__restrict__ l, const double *__restrict__ g, const double *__restrict__ c,
           const double *__restrict__ nz, const double *__restrict__ lo, const double *__restrict__ hi, double *__restrict__ s,
-          double *__restrict__ y, int32_t *__restrict__ mode, double *work, int *iwork, size_t wd, size_t wi)
+          double *__restrict__ y, int32_t *__restrict__ mode, double *work, int *iwork, size_t wd, size_t wi, int lds)
 {
     const int n = 6 * H, m = 12 * (H + 1), mg = m + 2 * n, nzc = 6 * H + 3 * H * (H + 1);
-    const size_t ldl = (size_t)(n + 1) * n / 2 + 1;
-    const lsqspmd::Work W = lsqspmd::carve(work + (size_t)blockIdx.x * wd, iwork + (size_t)blockIdx.x * wi, n, m, (int)blockDim.x);
+    const int ldl = (n + 1) * n / 2 + 1;
+    const lsqspmd::Work W = team_work(work, iwork, wd, wi, n, m, lds);
     const HipTeam T;
     for (int p = (int)blockIdx.x; p < count; p += (int)gridDim.x) {
-        const int md = lsqspmd::lsq(T, W, H, l + (size_t)p * ldl, g + (size_t)p * n, c + (size_t)p * m, nz + (size_t)p * nzc,
-                                    lo + (size_t)p * n, hi + (size_t)p * n, s + (size_t)p * n, y + (size_t)p * mg);
+        const double *lp = l + (size_t)p * ldl;
+        PAR_FOR(T, e, 0, ldl) W.E[e] = lp[e];
+        T.sync();
+        const int md = lsqspmd::lsq(T, W, H, g + (size_t)p * n, c + (size_t)p * m, nz + (size_t)p * nzc, lo + (size_t)p * n,
+                                    hi + (size_t)p * n, s + (size_t)p * n, y + (size_t)p * mg);
         if (threadIdx.x == 0) mode[p] = md;
         __syncthreads();
     }
@@ -34,17 +50,18 @@ qp_kernel(int H, int count, const double *__restrict__ l, const double *__restri
 // One major-iteration step of an offloaded solve (slsqp_core.h: slsqp_state.offload) for the problems listed
 // in `index`: reset or BFGS-update the problem's LDL' factor, solve the QP, keep the new multipliers and the
 // Lagrangian gradient v = g - (dc/dx)^T r for the next update.  State rows are addressed by problem, the
-// request's own arrays by position in the list.
+// request's own arrays by position in the list.  The factor is staged in the team's triangle (W.E), updated
+// there, written back, and then turned in place into the QP's e.
 __global__ void __launch_bounds__(mpck::kQpThreads)
 qp_step_kernel(int H, int count, const int32_t *__restrict__ index, const int32_t *__restrict__ flags,
                const double *__restrict__ lo, const double *__restrict__ hi, const double *__restrict__ s_in, double *L,
                const double *__restrict__ G, const double *__restrict__ C, const double *__restrict__ NZ, double *R, double *V,
                double *__restrict__ s_out, double *__restrict__ r_out, int32_t *__restrict__ mode, double *work, int *iwork,
-               size_t wd, size_t wi)
+               size_t wd, size_t wi, int lds)
 {
     const int n = 6 * H, m = 12 * (H + 1), mg = m + 2 * n, nzc = 6 * H + 3 * H * (H + 1);
-    const size_t ldl = (size_t)(n + 1) * n / 2 + 1;
-    const lsqspmd::Work W = lsqspmd::carve(work + (size_t)blockIdx.x * wd, iwork + (size_t)blockIdx.x * wi, n, m, (int)blockDim.x);
+    const int ldl = (n + 1) * n / 2 + 1;
+    const lsqspmd::Work W = team_work(work, iwork, wd, wi, n, m, lds);
     const HipTeam T;
     for (int k = (int)blockIdx.x; k < count; k += (int)gridDim.x) {
         const size_t p = (size_t)index[k];
@@ -52,14 +69,24 @@ qp_step_kernel(int H, int count, const int32_t *__restrict__ index, const int32_
         const double *g = G + p * n, *c = C + p * m, *nz = NZ + p * nzc;
         const int fl = flags[k];
         if (fl & 1) {                                            // the factor of the identity
-            PAR_FOR(T, e, 0, (int)ldl - 1) l[e] = 0.0;
+            PAR_FOR(T, e, 0, ldl - 1) W.E[e] = 0.0;
             T.sync();
-            PAR_FOR(T, i, 0, n) l[i * n - (i * (i - 1)) / 2] = 1.0;
-            T.sync();
+            PAR_FOR(T, i, 0, n) W.E[i * n - (i * (i - 1)) / 2] = 1.0;
+        } else {
+            PAR_FOR(T, e, 0, ldl - 1) W.E[e] = l[e];
         }
-        if (fl & 2) lsqspmd::bfgs_update(T, W, H, l, g, nz, r, v, s_in + (size_t)k * n, W.xs);
+        if (fl & 2) {
+            PAR_FOR(T, i, 0, n) {
+                W.bb[i] = v[i];
+                W.zz[i] = s_in[(size_t)k * n + i];
+            }
+            T.sync();
+            lsqspmd::bfgs_update(T, W, H, W.E, g, nz, r, W.bb, W.zz, W.xs);
+        }
         T.sync();
-        const int md = lsqspmd::lsq(T, W, H, l, g, c, nz, lo + (size_t)k * n, hi + (size_t)k * n, s_out + (size_t)k * n, r);
+        if (fl & 3) PAR_FOR(T, e, 0, ldl - 1) l[e] = W.E[e];
+        T.sync();
+        const int md = lsqspmd::lsq(T, W, H, g, c, nz, lo + (size_t)k * n, hi + (size_t)k * n, s_out + (size_t)k * n, r);
         T.sync();
         if (md == 1) {
             PAR_FOR(T, i, 0, n) {
@@ -79,20 +106,40 @@ qp_step_kernel(int H, int count, const int32_t *__restrict__ index, const int32_
     }
 }
 
+// LDS of one team, in bytes, when its small pool goes there (0: it stays in global memory).
+size_t lds_bytes(int H)
+{
+    const int n = 6 * H, m = 12 * (H + 1);
+    const size_t b = lsqspmd::small_doubles(n, m, mpck::kQpThreads) * sizeof(double) + lsqspmd::work_ints(n, m, mpck::kQpThreads) * sizeof(int);
+    return b <= mpck::kQpLdsLimit ? b : 0;
+}
+
 }  // namespace
 
 namespace mpck {
+
+int qp_teams_per_cu(int H)
+{
+    const size_t b = lds_bytes(H);
+    if (!b) return 4;
+    const int t = (int)(kQpLdsLimit / b);
+    return t < 1 ? 1 : (t > 4 ? 4 : t);
+}
 
 hipError_t launch_qp_step(int H, int count, int teams, const int32_t *index, const int32_t *flags, const double *lo,
                           const double *hi, const double *s_in, double *L, const double *G, const double *C, const double *NZ,
                           double *R, double *V, double *s_out, double *r_out, int32_t *mode, double *work, int *iwork,
                           hipStream_t stream)
 {
-    hipLaunchKernelGGL(qp_step_kernel, dim3((unsigned)teams), dim3(kQpThreads), 0, stream, H, count, index, flags, lo, hi, s_in,
-                       L, G, C, NZ, R, V, s_out, r_out, mode, work, iwork, qp_work_doubles(H), qp_work_ints(H));
+    const size_t lds = lds_bytes(H);
+    if (lds) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(qp_step_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(qp_step_kernel, dim3((unsigned)teams), dim3(kQpThreads), lds, stream, H, count, index, flags, lo, hi, s_in,
+                       L, G, C, NZ, R, V, s_out, r_out, mode, work, iwork, qp_work_doubles(H), qp_work_ints(H), lds ? 1 : 0);
     return hipGetLastError();
 }
-
 
 size_t qp_work_doubles(int H) { return lsqspmd::work_doubles(6 * H, 12 * (H + 1), kQpThreads); }
 size_t qp_work_ints(int H) { return lsqspmd::work_ints(6 * H, 12 * (H + 1), kQpThreads); }
@@ -101,8 +148,13 @@ hipError_t launch_qp(int H, int count, int teams, const double *l, const double 
                      const double *lo, const double *hi, double *s, double *y, int32_t *mode, double *work, int *iwork,
                      hipStream_t stream)
 {
-    hipLaunchKernelGGL(qp_kernel, dim3((unsigned)teams), dim3(kQpThreads), 0, stream, H, count, l, g, c, nz, lo, hi, s, y, mode,
-                       work, iwork, qp_work_doubles(H), qp_work_ints(H));
+    const size_t lds = lds_bytes(H);
+    if (lds) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(qp_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(qp_kernel, dim3((unsigned)teams), dim3(kQpThreads), lds, stream, H, count, l, g, c, nz, lo, hi, s, y, mode,
+                       work, iwork, qp_work_doubles(H), qp_work_ints(H), lds ? 1 : 0);
     return hipGetLastError();
 }
 

@@ -35,12 +35,15 @@ struct SerialTeam {
 
 #define PAR_FOR(T, i, lo, hi) for (int i = (lo) + (T).tid(); i < (hi); i += (T).size())
 
-// Workspace of one team (doubles unless noted).  mg = m + 2n, n1 = n + 1.
+// Workspace of one team (doubles unless noted).  mg = m + 2n, n1 = n + 1.  Two pools: the BIG one holds the two
+// matrices and lives in global memory; the SMALL one (the packed triangle and every vector) is what the serial
+// sections and the broadcast reads touch, and goes to LDS when it fits (kernels_qp.hip).
 struct Work {
-    double *E;     // [n*n]   e = sqrt(d) l^T, column-major, leading dimension n
-    double *ff;    // [n]
     double *G;     // [(n+1)*mg]: G[i + j*mg] = g(i, j) for j < n; G[i + n*mg] = h(i)
     double *AT;    // [(n+1)*mg]: the copy NNLS works on and overwrites (LDP needs g and h again afterwards)
+    double *E;     // [n(n+1)/2 + 1]: on entry the packed LDL' factor l; lsq turns it IN PLACE into e = sqrt(d) l^T,
+                   // e(r, c) for r <= c at E[off(r) + c - r], off(r) = r n - r(r-1)/2 (0-based), i.e. row by row
+    double *ff;    // [n]
     double *acc;   // [mg]
     double *bb;    // [n1]  NNLS right-hand side
     double *zz;    // [n1]
@@ -55,21 +58,23 @@ struct Work {
     int *isc;      // [16]
 };
 
-SPMD_HD inline size_t work_doubles(int n, int m, int team)
+SPMD_HD inline size_t big_doubles(int n, int m) { return 2 * ((size_t)n + 1) * ((size_t)m + 2 * (size_t)n); }
+SPMD_HD inline size_t small_doubles(int n, int m, int team)
 {
     const size_t mg = (size_t)m + 2 * (size_t)n, n1 = (size_t)n + 1;
-    return (size_t)n * n + n + 2 * n1 * mg + mg + n1 + n1 + mg + mg + n1 + n + 16 + (size_t)team;
+    return (size_t)n * n1 / 2 + 1 + n + mg + n1 + n1 + mg + mg + n1 + n + 16 + (size_t)team;
 }
+SPMD_HD inline size_t work_doubles(int n, int m, int team) { return big_doubles(n, m) + small_doubles(n, m, team); }
 SPMD_HD inline size_t work_ints(int n, int m, int team) { return (size_t)team + (size_t)m + 2 * (size_t)n + 16; }
 
-SPMD_HD inline Work carve(double *d, int *i, int n, int m, int team)
+SPMD_HD inline Work carve(double *big, double *d, int *i, int n, int m, int team)
 {
     const size_t mg = (size_t)m + 2 * (size_t)n, n1 = (size_t)n + 1;
     Work W;
-    W.E = d;            d += (size_t)n * n;
+    W.G = big;
+    W.AT = big + n1 * mg;
+    W.E = d;            d += (size_t)n * n1 / 2 + 1;
     W.ff = d;           d += n;
-    W.G = d;            d += n1 * mg;
-    W.AT = d;           d += n1 * mg;
     W.acc = d;          d += mg;
     W.bb = d;           d += n1;
     W.zz = d;           d += n1;
@@ -154,53 +159,52 @@ SPMD_HD int nnls(const Team &T, const Work &W, int mrow, int ncol, int mg, doubl
             if (W.sc[0] <= 0.0) { accepted = -1; break; }      // exit loop A
             iz = W.isc[0];
             j = index[iz - 1];
-            // ---- step four: test column j for linear dependence (thread 0)
+            // ---- step four: test column j for linear dependence (thread 0, on a copy of the column: only the
+            //      new pivot entry is written back, and only when the column is accepted)
+            PAR_FOR(T, r, 0, m) { W.piv[r] = AT(r + 1, j); z[r] = b[r]; }
+            T.sync();
             if (T.tid() == 0) {
-                const double asave = AT(npp1, j);
+                double *pc = W.piv;                  // pc[r - 1] = a(r, j)
                 // h12 construct on rows npp1..m of column j
-                double cl = fabs(AT(npp1, j)), upv = 0.0;
+                double cl = fabs(pc[npp1 - 1]), upv = 0.0;
                 int ok = 1;
                 if (npp1 + 1 <= m) {               // h12 does nothing when l1 > m
-                    for (int r = npp1 + 1; r <= m; ++r) { const double sm = fabs(AT(r, j)); cl = sm > cl ? sm : cl; }
+                    for (int r = npp1 + 1; r <= m; ++r) { const double sm = fabs(pc[r - 1]); cl = sm > cl ? sm : cl; }
                     if (cl > 0.0) {
                         const double clinv = 1.0 / cl;
-                        double sm = (AT(npp1, j) * clinv) * (AT(npp1, j) * clinv);
-                        for (int r = npp1 + 1; r <= m; ++r) sm = sm + (AT(r, j) * clinv) * (AT(r, j) * clinv);
+                        double sm = (pc[npp1 - 1] * clinv) * (pc[npp1 - 1] * clinv);
+                        for (int r = npp1 + 1; r <= m; ++r) sm = sm + (pc[r - 1] * clinv) * (pc[r - 1] * clinv);
                         cl = cl * sqrt(sm);
-                        if (AT(npp1, j) > 0.0) cl = -cl;
-                        upv = AT(npp1, j) - cl;
-                        AT(npp1, j) = cl;
+                        if (pc[npp1 - 1] > 0.0) cl = -cl;
+                        upv = pc[npp1 - 1] - cl;
+                        pc[npp1 - 1] = cl;
                     }
                 }
                 {
-                    // unorm over the rows already in the triangle (stride mg in this storage)
-                    const double unorm = nrm2(nsetp, &AT(1, j), mg);
-                    const double t = factor * fabs(AT(npp1, j));
+                    const double unorm = nrm2(nsetp, pc, 1);         // the rows already in the triangle
+                    const double t = factor * fabs(pc[npp1 - 1]);
                     volatile double d = unorm + t;
                     if (d - unorm <= 0.0) ok = 0;
                 }
                 if (ok) {
-                    for (int r = 0; r < m; ++r) z[r] = b[r];
-                    // h12 apply (mode 2) to z with pivot npp1, l1 = npp1 + 1
-                    if (npp1 + 1 <= m && fabs(AT(npp1, j)) > 0.0) {
-                        double bq = upv * AT(npp1, j);
+                    // h12 apply (mode 2) to z (= b) with pivot npp1, l1 = npp1 + 1
+                    if (npp1 + 1 <= m && fabs(pc[npp1 - 1]) > 0.0) {
+                        double bq = upv * pc[npp1 - 1];
                         if (bq < 0.0) {
                             bq = 1.0 / bq;
                             double sm = z[npp1 - 1] * upv;
-                            for (int r = npp1 + 1; r <= m; ++r) sm = sm + z[r - 1] * AT(r, j);
+                            for (int r = npp1 + 1; r <= m; ++r) sm = sm + z[r - 1] * pc[r - 1];
                             if (sm != 0.0) {
                                 sm = sm * bq;
                                 z[npp1 - 1] = z[npp1 - 1] + sm * upv;
-                                for (int r = npp1 + 1; r <= m; ++r) z[r - 1] = z[r - 1] + sm * AT(r, j);
+                                for (int r = npp1 + 1; r <= m; ++r) z[r - 1] = z[r - 1] + sm * pc[r - 1];
                             }
                         }
                     }
-                    if (!(z[npp1 - 1] / AT(npp1, j) > 0.0)) ok = 0;
+                    if (!(z[npp1 - 1] / pc[npp1 - 1] > 0.0)) ok = 0;
                 }
-                if (!ok) {
-                    AT(npp1, j) = asave;
-                    w[j - 1] = 0.0;
-                }
+                if (ok) AT(npp1, j) = pc[npp1 - 1];
+                else w[j - 1] = 0.0;
                 W.isc[1] = ok;
                 W.sc[1] = upv;
             }
@@ -209,7 +213,7 @@ SPMD_HD int nnls(const Team &T, const Work &W, int mrow, int ncol, int mg, doubl
         }
         if (accepted < 0) break;
         // ---- step five: column j enters the set
-        PAR_FOR(T, r, 0, m) { b[r] = z[r]; W.piv[r] = AT(r + 1, j); }
+        PAR_FOR(T, r, 0, m) b[r] = z[r];                   // W.piv already holds the column with its new pivot
         T.sync();
         if (T.tid() == 0) {
             index[iz - 1] = index[iz1 - 1];
@@ -353,109 +357,162 @@ SPMD_HD int nnls(const Team &T, const Work &W, int mrow, int ncol, int mg, doubl
 #undef AT
 }
 
-// Kraft's LSQ for the MPC shape.  l: packed LDL' factor ((n+1)n/2 + 1 entries), g: gradient, cvals: c(x),
-// nz: structured dc/dx, lo / hi: bounds on the step (xl - x, xu - x).  Returns the mode (1 = solved) and
-// writes the step s [n] and the multipliers y [m + 2n] (the bound rows' multipliers follow the m
-// constraint rows; slsqp_core.c overwrites those with NaN, they are unused).
+// Kraft's LSQ for the MPC shape.  W.E holds the packed LDL' factor l on entry ((n+1)n/2 + 1 entries; it is
+// overwritten), g: gradient, cvals: c(x), nz: structured dc/dx, lo / hi: bounds on the step (xl - x, xu - x).
+// Returns the mode (1 = solved) and writes the step s [n] and the multipliers y [m + 2n] (the bound rows'
+// multipliers follow the m constraint rows; slsqp_core.c overwrites those with NaN, they are unused).
+//
+// Where the text below departs from a literal reading of slsqp_core.c, the arithmetic is still the same:
+//   * rows of [g h] are generated from nz and the bounds instead of being read from a zero-filled matrix, and the
+//     terms of a row's sums that come before its first nonzero are left out: they add (+-0) * e to a sum that is
+//     +0.0, which leaves +0.0;
+//   * sums against the NNLS solution skip its exact zeros (every entry outside the final set): t + a * 0.0 is t for
+//     finite a, and t is never -0.0.
 template <class Team>
-SPMD_HD int lsq(const Team &T, const Work &W, int H, const double *l, const double *g, const double *cvals, const double *nz,
-                const double *lo, const double *hi, double *s, double *y)
+SPMD_HD int lsq(const Team &T, const Work &W, int H, const double *g, const double *cvals, const double *nz, const double *lo,
+                const double *hi, double *s, double *y)
 {
     const int n = 6 * H, m = 12 * (H + 1), mg = m + 2 * n;
-#define E(i, j) W.E[((i) - 1) + (size_t)((j) - 1) * n]
-#define G(i, j) W.G[((i) - 1) + (size_t)((j) - 1) * mg]
-    // ---- e = sqrt(d) l^T (upper triangular) and g with the constraint rows, +I, -I
-    PAR_FOR(T, e, 0, n * n) {
-        const int r = e % n, c = e / n;            // 0-based row, column
-        double v = 0.0;
-        if (r <= c) {
-            const int off = r * n - (r * (r - 1)) / 2;
-            const double diag = sqrt(l[off]);
-            v = (r == c) ? diag : diag * l[off + (c - r)];
-        }
-        W.E[e] = v;
+#define EO(r) ((r) * n - ((r) * ((r) - 1)) / 2)
+    // ---- e = sqrt(d) l^T in place (row r of e is column r of l scaled by sqrt(d_r))
+    PAR_FOR(T, i, 0, n) {
+        W.piv[i] = sqrt(W.E[EO(i)]);
+        W.xs[i] = g[i];
+        W.acc[i] = 0.0;
     }
-    PAR_FOR(T, e, 0, n * mg) W.G[e] = 0.0;
+    if (T.tid() == 0) W.isc[8] = 1;
     T.sync();
-    PAR_FOR(T, k, 0, 6 * H + 3 * H * (H + 1)) {
-        int row, col;
-        if (k < 6 * H) {                            // velocity row of state j+1
-            col = k;
-            row = 12 * (k / 6 + 1) + 6 + k % 6;
-        } else {                                    // position rows: k = 6H + 6*T(j,kk) + a
-            const int q = (k - 6 * H) / 6, a = (k - 6 * H) % 6;
-            int j = 0, base = 0;                    // T(j, kk) = base_j + (kk - j - 1), base_j = j*H - j(j-1)/2
-            while (j + 1 < H && (j + 1) * H - ((j + 1) * j) / 2 <= q) ++j;
-            base = j * H - (j * (j - 1)) / 2;
-            const int kk = q - base + j + 1;
-            col = 6 * j + a;
-            row = 12 * kk + a;
-        }
-        W.G[row + (size_t)col * mg] = nz[k];
+    PAR_FOR(T, r, 0, n) {
+        double *er = W.E + EO(r);
+        const double d = W.piv[r];
+        er[0] = d;
+        for (int c = 1; c < n - r; ++c) er[c] = d * er[c];
     }
-    PAR_FOR(T, i, 0, m) W.G[i + (size_t)n * mg] = -cvals[i];                 // h = -b
-    PAR_FOR(T, v, 0, n) {
-        W.G[(m + v) + (size_t)v * mg] = 1.0;
-        W.G[(m + n + v) + (size_t)v * mg] = -1.0;
-        W.G[(m + v) + (size_t)n * mg] = lo[v];
-        W.G[(m + n + v) + (size_t)n * mg] = -hi[v];
-    }
-    // ---- f: solve e^T f = g by forward substitution, then negate (thread 0: a recurrence)
     T.sync();
-    if (T.tid() == 0) {
-        for (int i = 1; i <= n; ++i) {
-            double t = 0.0;
-            for (int k = 1; k < i; ++k) t = t + E(k, i) * W.ff[k - 1];
-            W.ff[i - 1] = (g[i - 1] - t) / E(i, i);
+    // ---- f: solve e^T f = g by forward substitution, column-oriented: once f(k) is known every later row adds its
+    //      term e(k, i) f(k), which it does in the order k = 0, 1, ... of the serial dot product; the thread that
+    //      owns row k + 1 (always thread 0) finishes f(k + 1) in the same sweep.  Then negate.
+    if (T.tid() == 0) W.ff[0] = (W.xs[0] - 0.0) / W.E[0];
+    T.sync();
+    for (int k = 0; k + 1 < n; ++k) {
+        const double fk = W.ff[k];
+        const double *ek = W.E + EO(k) - k;            // ek[i] = e(k, i)
+        PAR_FOR(T, i, k + 1, n) {
+            const double t = W.acc[i] + ek[i] * fk;
+            W.acc[i] = t;
+            if (i == k + 1) W.ff[i] = (W.xs[i] - t) / W.E[EO(i)];
         }
-        for (int i = 0; i < n; ++i) W.ff[i] = -1.0 * W.ff[i];
-        // ---- LSI: "QR" of the triangular e (pivot arithmetic only, see slsqp_core.c) applied to f
-        for (int i = 1; i <= n; ++i) {
-            double cl = fabs(E(i, i));
-            if (i + 1 > n || cl <= 0.0) continue;
-            const double clinv = 1.0 / cl;
-            double sm = (E(i, i) * clinv) * (E(i, i) * clinv);
-            cl = cl * sqrt(sm);
-            if (E(i, i) > 0.0) cl = -cl;
-            const double up = E(i, i) - cl;
-            E(i, i) = cl;
-            double bq = up * E(i, i);
-            if (bq >= 0.0) continue;
-            bq = 1.0 / bq;
-            for (int j = i + 1; j <= n; ++j) {
-                sm = E(i, j) * up;
-                if (sm == 0.0) continue;
-                sm = sm * bq;
-                E(i, j) = E(i, j) + sm * up;
-            }
-            sm = W.ff[i - 1] * up;
-            if (sm != 0.0) {
-                sm = sm * bq;
-                W.ff[i - 1] = W.ff[i - 1] + sm * up;
-            }
-        }
-        int regular = 1;
-        for (int j = 1; j <= n; ++j)
-            if (!(fabs(E(j, j)) >= 2.22e-16)) regular = 0;
-        W.isc[8] = regular;
+        T.sync();
     }
+    PAR_FOR(T, i, 0, n) W.ff[i] = -1.0 * W.ff[i];
+    T.sync();
+    // ---- LSI: "QR" of the triangular e (pivot arithmetic only, see slsqp_core.c) applied to f: a row touches
+    //      nothing but itself, one row per index
+    PAR_FOR(T, i, 0, n - 1) {
+        double *er = W.E + EO(i);
+        const double eii = er[0];
+        double cl = fabs(eii);
+        if (cl <= 0.0) continue;
+        const double clinv = 1.0 / cl;
+        double sm = (eii * clinv) * (eii * clinv);
+        cl = cl * sqrt(sm);
+        if (eii > 0.0) cl = -cl;
+        const double up = eii - cl;
+        er[0] = cl;
+        double bq = up * cl;
+        if (bq >= 0.0) continue;
+        bq = 1.0 / bq;
+        for (int c = 1; c < n - i; ++c) {
+            sm = er[c] * up;
+            if (sm == 0.0) continue;
+            sm = sm * bq;
+            er[c] = er[c] + sm * up;
+        }
+        sm = W.ff[i] * up;
+        if (sm != 0.0) {
+            sm = sm * bq;
+            W.ff[i] = W.ff[i] + sm * up;
+        }
+    }
+    T.sync();
+    PAR_FOR(T, j, 0, n)
+        if (!(fabs(W.E[EO(j)]) >= 2.22e-16)) W.isc[8] = 0;
     T.sync();
     if (!W.isc[8]) return 5;
-    // ---- g <- g e^-1, h <- h - g f: one row per index, sums in the order of the serial text
+    // ---- [g h] <- [g e^-1, h - g f]: one row per index, six columns at a time so that an earlier entry of the row
+    //      is read once per block; every sum still runs over k in ascending order.  Written to G and to AT.
     PAR_FOR(T, i, 0, mg) {
-        double *gi = W.G + i;
-        for (int j = 1; j <= n; ++j) {
-            double t = 0.0;
-            for (int k = 1; k < j; ++k) t = t + gi[(size_t)(k - 1) * mg] * E(k, j);
-            gi[(size_t)(j - 1) * mg] = (gi[(size_t)(j - 1) * mg] - t) / E(j, j);
+        int a = 0, first = H, last = -1, kind = 0, kk = 0;      // block range [first, last] holds the row's nonzeros
+        double hval;
+        if (i < m) {
+            const int st = i / 12, r = i % 12;
+            hval = -cvals[i];
+            if (r < 6) { a = r; kk = st; if (st >= 1) { first = 0; last = st - 1; kind = 1; } }        // position row
+            else { a = r - 6; if (st >= 1) { first = st - 1; last = st - 1; kind = 2; } }              // velocity row
+        } else if (i < m + n) {
+            const int v = i - m;
+            a = v % 6; first = v / 6; last = first; kind = 3; hval = lo[v];
+        } else {
+            const int v = i - m - n;
+            a = v % 6; first = v / 6; last = first; kind = 4; hval = -hi[v];
         }
-        double t = 0.0;
-        for (int j = 1; j <= n; ++j) t = t + gi[(size_t)(j - 1) * mg] * W.ff[j - 1];
-        gi[(size_t)n * mg] = gi[(size_t)n * mg] - t;
+        double *gi = W.G + i, *ai = W.AT + i;
+        const int kfirst = 6 * first;
+        double th = 0.0;
+        for (int jj = 0; jj < H; ++jj) {
+            const int jb = 6 * jj;
+            if (jj < first) {
+                for (int c = 0; c < 6; ++c) {
+                    const double res = (0.0 - 0.0) / W.E[EO(jb + c)];
+                    gi[(size_t)(jb + c) * mg] = res;
+                    ai[(size_t)(jb + c) * mg] = res;
+                }
+                continue;
+            }
+            double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0, a4 = 0.0, a5 = 0.0;
+            {
+                const double *er = W.E + jb;               // er[c] = e(k, jb + c), advanced row by row
+                for (int k = 0; k < jb; ++k) {
+                    if (k >= kfirst) {
+                        const double gk = ai[(size_t)k * mg];
+                        a0 = a0 + gk * er[0];
+                        a1 = a1 + gk * er[1];
+                        a2 = a2 + gk * er[2];
+                        a3 = a3 + gk * er[3];
+                        a4 = a4 + gk * er[4];
+                        a5 = a5 + gk * er[5];
+                    }
+                    er += n - k - 1;
+                }
+            }
+            double val = 0.0;
+            if (jj <= last) {
+                if (kind == 1) val = nz[6 * H + 6 * (jj * H - (jj * (jj - 1)) / 2 - jj - 1 + kk) + a];
+                else if (kind == 2) val = nz[6 * jj + a];
+                else val = (kind == 3) ? 1.0 : -1.0;
+            }
+            double gn[6], ac[6] = {a0, a1, a2, a3, a4, a5};
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+            for (int c = 0; c < 6; ++c) {
+                double t = ac[c];
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+                for (int c2 = 0; c2 < c; ++c2) t = t + gn[c2] * W.E[EO(jb + c2) + (c - c2)];
+                const double orig = (c == a && jj <= last) ? val : 0.0;
+                gn[c] = (orig - t) / W.E[EO(jb + c)];
+                gi[(size_t)(jb + c) * mg] = gn[c];
+                ai[(size_t)(jb + c) * mg] = gn[c];
+                th = th + gn[c] * W.ff[jb + c];
+            }
+        }
+        const double res = hval - th;
+        gi[(size_t)n * mg] = res;
+        ai[(size_t)n * mg] = res;
     }
-    // ---- LDP: NNLS on a copy of [g h]^T with right-hand side e_{n+1}
-    T.sync();
-    PAR_FOR(T, e, 0, (n + 1) * mg) W.AT[e] = W.G[e];
+    // ---- LDP: NNLS on the copy of [g h]^T with right-hand side e_{n+1}
     PAR_FOR(T, i, 0, n) W.bb[i] = 0.0;
     if (T.tid() == 0) W.bb[n] = 1.0;
     T.sync();
@@ -465,10 +522,19 @@ SPMD_HD int lsq(const Team &T, const Work &W, int H, const double *l, const doub
     rnorm = W.sc[2];
     if (mode != 1) return mode;
     if (rnorm <= 0.0) return 4;
-    if (T.tid() == 0) {
+    // ---- column sums against the NNLS solution (column n is h): only the rows in the final set contribute
+    PAR_FOR(T, j, 0, n + 1) {
+        const double *gj = W.G + (size_t)j * mg;
         double t = 0.0;
-        for (int i = 0; i < mg; ++i) t = t + W.G[i + (size_t)n * mg] * W.xn[i];       // ddot(m, h, y)
-        const double fac = 1.0 - t;
+        for (int i = 0; i < mg; ++i) {
+            const double xi = W.xn[i];
+            if (xi != 0.0) t = t + gj[i] * xi;
+        }
+        W.zz[j] = t;
+    }
+    T.sync();
+    if (T.tid() == 0) {
+        const double fac = 1.0 - W.zz[n];                 // 1 - ddot(m, h, y)
         volatile double d = 1.0 + fac;
         W.isc[9] = (d - 1.0 > 0.0) ? 1 : 0;
         W.sc[3] = fac;
@@ -476,20 +542,17 @@ SPMD_HD int lsq(const Team &T, const Work &W, int H, const double *l, const doub
     T.sync();
     if (!W.isc[9]) return 4;
     const double fac = 1.0 / W.sc[3];
-    PAR_FOR(T, j, 0, n) {
-        double t = 0.0;
-        for (int i = 0; i < mg; ++i) t = t + W.G[i + (size_t)j * mg] * W.xn[i];
-        W.xs[j] = fac * t;
-    }
+    PAR_FOR(T, j, 0, n) W.xs[j] = fac * W.zz[j];
     PAR_FOR(T, i, 0, mg) y[i] = 0.0 + fac * W.xn[i];
     T.sync();
     // ---- back to the original variables: x = e^-1 (x + f), then the box (thread 0: a recurrence)
     if (T.tid() == 0) {
         for (int i = 0; i < n; ++i) W.xs[i] = W.xs[i] + 1.0 * W.ff[i];
-        for (int i = n; i >= 1; --i) {
+        for (int i = n - 1; i >= 0; --i) {
+            const double *er = W.E + EO(i) - i;            // er[j] = e(i, j)
             double t = 0.0;
-            for (int j = i + 1; j <= n; ++j) t = t + E(i, j) * W.xs[j - 1];
-            W.xs[i - 1] = (W.xs[i - 1] - t) / E(i, i);
+            for (int j = i + 1; j < n; ++j) t = t + er[j] * W.xs[j];
+            W.xs[i] = (W.xs[i] - t) / er[i];
         }
         for (int i = 0; i < n; ++i) {
             double v = W.xs[i];
@@ -500,8 +563,7 @@ SPMD_HD int lsq(const Team &T, const Work &W, int H, const double *l, const doub
     }
     T.sync();
     return 1;
-#undef E
-#undef G
+#undef EO
 }
 
 // Rank-one update of the LDL' factorisation a (packed by columns) with z and sigma; w is work (Fletcher &

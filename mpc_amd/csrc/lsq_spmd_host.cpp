@@ -26,8 +26,9 @@ extern "C" void mpc_lsq_spmd_serial(int m, int meq, int n, int nl, int la, doubl
             for (int k = j + 1; k <= H; ++k) nz[6 * H + 6 * (tri + k) + q] = a[(12 * k + q) + (size_t)col * la];
         }
     }
-    lsqspmd::Work W = lsqspmd::carve(dw.data(), iw.data(), n, m, 1);
-    *mode = lsqspmd::lsq(lsqspmd::SerialTeam(), W, H, l, g, b, nz.data(), xl, xu, x, yy.data());
+    lsqspmd::Work W = lsqspmd::carve(dw.data(), dw.data() + lsqspmd::big_doubles(n, m), iw.data(), n, m, 1);
+    for (int e = 0; e < nl; ++e) W.E[e] = l[e];                  // lsq works on its own copy of the factor
+    *mode = lsqspmd::lsq(lsqspmd::SerialTeam(), W, H, g, b, nz.data(), xl, xu, x, yy.data());
     if (*mode == 1) {
         for (int i = 0; i < m; ++i) y[i] = yy[i];
         for (int i = m; i < m + 2 * n; ++i) y[i] = NAN;
@@ -53,6 +54,6 @@ extern "C" void mpc_bfgs_spmd_serial(int m, int n, int la, double *l, double *g,
             for (int k = j + 1; k <= H; ++k) nz[6 * H + 6 * (tri + k) + q] = a[(12 * k + q) + (size_t)col * la];
         }
     }
-    lsqspmd::Work W = lsqspmd::carve(dw.data(), iw.data(), n, m, 1);
+    lsqspmd::Work W = lsqspmd::carve(dw.data(), dw.data() + lsqspmd::big_doubles(n, m), iw.data(), n, m, 1);
     lsqspmd::bfgs_update(lsqspmd::SerialTeam(), W, H, l, g, nz.data(), r, v, s, u);
 }

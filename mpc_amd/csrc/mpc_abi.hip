@@ -334,10 +334,10 @@ namespace {
 int qp_workspace(mpc_ctx *ctx)
 {
     if (ctx->d_qp_work) return MPC_OK;
-    // up to four resident workgroups per CU; each owns ~1.1 MB of workspace at H = 20
+    // as many teams as stay resident (LDS decides: two per CU at H = 20); each owns ~1 MB of workspace at H = 20
     hipDeviceProp_t prop;
     MPC_HIP(ctx, hipGetDeviceProperties(&prop, ctx->device));
-    int teams = 4 * prop.multiProcessorCount;
+    int teams = mpck::qp_teams_per_cu(ctx->horizon) * prop.multiProcessorCount;
     if (teams > ctx->max_scenarios) teams = ctx->max_scenarios;
     const size_t wd = mpck::qp_work_doubles(ctx->horizon), wi = mpck::qp_work_ints(ctx->horizon);
     while (teams > 1 && (size_t)teams * wd * sizeof(double) > (size_t(4) << 30)) teams /= 2;

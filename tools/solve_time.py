@@ -52,6 +52,22 @@ def main():
             t3 = time.perf_counter()
         print(f"native T={W} M={k}: solve {t3-t2:.2f}s -> {k/(t3-t2):.1f} solves/s; core_max={r.t_core:.2f} serve={r.t_serve:.2f} "
               f"rounds={r.rounds} conv={int(r.success.sum())}", flush=True)
+    from mpc_amd.native_solver import DeviceQpSLSQP
+    for M2 in (PER_WORKER * max(Ws), 4 * PER_WORKER * max(Ws)):
+        if M2 > M:
+            hs2 = make_scenarios(mp, DeviceKinematics(ctx), M2, motion="angular", cfg_id=3, goal_jitter=0.0)
+            ctx2 = MpcContext(mp, M2, 0)
+            sc2, _ = to_device(ctx2, hs2)
+            x02 = np.tile(hs2.u_init, (1, 20))
+        else:
+            ctx2, sc2, x02 = ctx, sc_all.slice(0, M2), x0[:M2]
+        with DeviceQpSLSQP(ctx2, threads=max(Ws), capacity=M2) as dev:
+            dev.solve(sc2.slice(0, 8), x02[:8])   # warm
+            t2 = time.perf_counter()
+            r = dev.solve(sc2, x02)
+            t3 = time.perf_counter()
+        print(f"device-QP T={max(Ws)} M={M2}: solve {t3-t2:.2f}s -> {M2/(t3-t2):.1f} solves/s; core_sum={r.t_core:.2f} evals={r.t_serve:.2f} "
+              f"qp={r.t_qp:.2f} ({r.n_qp} QPs) rounds={r.rounds} conv={int(r.success.sum())} host_fallback={r.n_host_fallback}", flush=True)
 
 
 if __name__ == "__main__":
