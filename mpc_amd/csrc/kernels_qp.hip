@@ -6,6 +6,10 @@
 #include "lsq_spmd.hpp"
 #include "mpc_kernels.hpp"
 
+#ifndef MPC_QP_WAVES
+#define MPC_QP_WAVES 4
+#endif
+
 namespace {
 
 struct HipTeam {
@@ -27,7 +31,7 @@ __device__ lsqspmd::Work team_work(double *work, int *iwork, size_t wd, size_t w
                           (int)blockDim.x);
 }
 
-__global__ void __launch_bounds__(mpck::kQpThreads)
+__global__ void __launch_bounds__(mpck::kQpThreads, MPC_QP_WAVES)
 qp_kernel(int H, int count, const double *__restrict__ l, const double *__restrict__ g, const double *__restrict__ c,
           const double *__restrict__ nz, const double *__restrict__ lo, const double *__restrict__ hi, double *__restrict__ s,
           double *__restrict__ y, int32_t *__restrict__ mode, double *work, int *iwork, size_t wd, size_t wi, int lds)
@@ -52,7 +56,7 @@ qp_kernel(int H, int count, const double *__restrict__ l, const double *__restri
 // Lagrangian gradient v = g - (dc/dx)^T r for the next update.  State rows are addressed by problem, the
 // request's own arrays by position in the list.  The factor is staged in the team's triangle (W.E), updated
 // there, written back, and then turned in place into the QP's e.
-__global__ void __launch_bounds__(mpck::kQpThreads)
+__global__ void __launch_bounds__(mpck::kQpThreads, MPC_QP_WAVES)
 qp_step_kernel(int H, int count, const int32_t *__restrict__ index, const int32_t *__restrict__ flags,
                const double *__restrict__ lo, const double *__restrict__ hi, const double *__restrict__ s_in, double *L,
                const double *__restrict__ G, const double *__restrict__ C, const double *__restrict__ NZ, double *R, double *V,

@@ -44,7 +44,7 @@ struct Work {
     double *E;     // [n(n+1)/2 + 1]: on entry the packed LDL' factor l; lsq turns it IN PLACE into e = sqrt(d) l^T,
                    // e(r, c) for r <= c at E[off(r) + c - r], off(r) = r n - r(r-1)/2 (0-based), i.e. row by row
     double *ff;    // [n]
-    double *acc;   // [mg]
+    double *acc;   // [max(mg, team size)]; NNLS's reduction (redv) borrows it
     double *bb;    // [n1]  NNLS right-hand side
     double *zz;    // [n1]
     double *xn;    // [mg]  NNLS solution (dual variables of LDP)
@@ -52,7 +52,7 @@ struct Work {
     double *piv;   // [n1]  copy of the pivot column
     double *xs;    // [n]
     double *sc;    // [16]  scalars broadcast from thread 0
-    double *redv;  // [team size]
+    double *redv;  // = acc
     int *redi;     // [team size]
     int *idx;      // [mg]
     int *isc;      // [16]
@@ -62,7 +62,8 @@ SPMD_HD inline size_t big_doubles(int n, int m) { return 2 * ((size_t)n + 1) * (
 SPMD_HD inline size_t small_doubles(int n, int m, int team)
 {
     const size_t mg = (size_t)m + 2 * (size_t)n, n1 = (size_t)n + 1;
-    return (size_t)n * n1 / 2 + 1 + n + mg + n1 + n1 + mg + mg + n1 + n + 16 + (size_t)team;
+    const size_t accn = mg > (size_t)team ? mg : (size_t)team;
+    return (size_t)n * n1 / 2 + 1 + n + accn + n1 + n1 + mg + mg + n1 + n + 16;
 }
 SPMD_HD inline size_t work_doubles(int n, int m, int team) { return big_doubles(n, m) + small_doubles(n, m, team); }
 SPMD_HD inline size_t work_ints(int n, int m, int team) { return (size_t)team + (size_t)m + 2 * (size_t)n + 16; }
@@ -75,15 +76,15 @@ SPMD_HD inline Work carve(double *big, double *d, int *i, int n, int m, int team
     W.AT = big + n1 * mg;
     W.E = d;            d += (size_t)n * n1 / 2 + 1;
     W.ff = d;           d += n;
-    W.acc = d;          d += mg;
+    W.acc = d;          d += mg > (size_t)team ? mg : (size_t)team;
     W.bb = d;           d += n1;
     W.zz = d;           d += n1;
     W.xn = d;           d += mg;
     W.wd = d;           d += mg;
     W.piv = d;          d += n1;
     W.xs = d;           d += n;
-    W.sc = d;           d += 16;
-    W.redv = d;
+    W.sc = d;
+    W.redv = W.acc;
     W.redi = i;         i += team;
     W.idx = i;          i += mg;
     W.isc = i;
@@ -125,7 +126,10 @@ SPMD_HD int nnls(const Team &T, const Work &W, int mrow, int ncol, int mg, doubl
         PAR_FOR(T, t, iz1 - 1, iz2) {
             const int j = index[t];
             double s = 0.0;
-            for (int r = npp1; r <= m; ++r) s = s + AT(r, j) * b[r - 1];
+            for (int r = npp1; r <= m; ++r) {
+                const double br = b[r - 1];                 // a * (+-0.0) added to a sum that is never -0.0: no change
+                if (br != 0.0) s = s + AT(r, j) * br;
+            }
             w[j - 1] = s;
         }
         T.sync();
@@ -357,6 +361,114 @@ SPMD_HD int nnls(const Team &T, const Work &W, int mrow, int ncol, int mg, doubl
 #undef AT
 }
 
+// Row i of [g h] <- [g e^-1, h - g f] for the MPC's constraint matrix, written to dst[j * mg], j = 0..n (entry n is
+// h).  The row is generated from the structured Jacobian / the bounds; columns are taken NB * 6 at a time so that an
+// earlier entry of the row is read back once per block, and every sum runs over k in ascending order as in the
+// serial text.  Terms before the row's first nonzero are left out (they add +-0.0 to a sum that is +0.0).
+template <int NB>
+SPMD_HD inline void transform_cols(const Work &W, int n, int mg, int H, const double *nz, double *dst, int jj0, int first,
+                                   int last, int kind, int kk, int a, double &th)
+{
+    constexpr int NC = 6 * NB;
+    const int jb = 6 * jj0;
+#define EO(r) ((r) * n - ((r) * ((r) - 1)) / 2)
+    double acc[NC];
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+    for (int c = 0; c < NC; ++c) acc[c] = 0.0;
+    {
+        const double *er = W.E + jb;                       // er[c] = e(k, jb + c), advanced row by row
+        for (int kb = 0; kb < jj0; ++kb) {
+            if (kb >= first) {
+                double gk[6];
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+                for (int q = 0; q < 6; ++q) gk[q] = dst[(size_t)(6 * kb + q) * mg];
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+                for (int q = 0; q < 6; ++q) {
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+                    for (int c = 0; c < NC; ++c) acc[c] = acc[c] + gk[q] * er[c];
+                    er += n - (6 * kb + q) - 1;
+                }
+            } else {
+                er += 6 * (n - 6 * kb - 1) - 15;
+            }
+        }
+    }
+    double val[NB];
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+    for (int b = 0; b < NB; ++b) {
+        const int jj = jj0 + b;
+        val[b] = 0.0;
+        if (jj >= first && jj <= last) {
+            if (kind == 1) val[b] = nz[6 * H + 6 * (jj * H - (jj * (jj - 1)) / 2 - jj - 1 + kk) + a];
+            else if (kind == 2) val[b] = nz[6 * jj + a];
+            else val[b] = (kind == 3) ? 1.0 : -1.0;
+        }
+    }
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+    for (int c = 0; c < NC; ++c) {
+        double t = acc[c];
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+        for (int c2 = 0; c2 < c; ++c2) t = t + acc[c2] * W.E[EO(jb + c2) + (c - c2)];   // acc[c2] holds the new g(i, jb + c2)
+        const double orig = (c % 6 == a) ? val[c / 6] : 0.0;
+        const double gn = (orig - t) / W.E[EO(jb + c)];
+        acc[c] = gn;
+        dst[(size_t)(jb + c) * mg] = gn;
+        th = th + gn * W.ff[jb + c];
+    }
+#undef EO
+}
+
+SPMD_HD inline void transform_row(const Work &W, int H, int i, const double *cvals, const double *nz, const double *lo,
+                                  const double *hi, double *dst)
+{
+    const int n = 6 * H, m = 12 * (H + 1), mg = m + 2 * n;
+    int a = 0, first = H, last = -1, kind = 0, kk = 0;      // sub-blocks [first, last] hold the row's nonzeros
+    double hval;
+    if (i < m) {
+        const int st = i / 12, r = i % 12;
+        hval = -cvals[i];
+        if (r < 6) { a = r; kk = st; if (st >= 1) { first = 0; last = st - 1; kind = 1; } }        // position row
+        else { a = r - 6; if (st >= 1) { first = st - 1; last = st - 1; kind = 2; } }              // velocity row
+    } else if (i < m + n) {
+        const int v = i - m;
+        a = v % 6; first = v / 6; last = first; kind = 3; hval = lo[v];
+    } else {
+        const int v = i - m - n;
+        a = v % 6; first = v / 6; last = first; kind = 4; hval = -hi[v];
+    }
+    double th = 0.0;
+    int jj = 0;
+#ifndef MPC_QP_NB
+#define MPC_QP_NB 4
+#endif
+    for (; jj + MPC_QP_NB <= H; jj += MPC_QP_NB) {
+        if (jj + MPC_QP_NB <= first) {                      // all zeros so far: (0 - 0) / e(j, j)
+            for (int c = 0; c < 6 * MPC_QP_NB; ++c) {
+                const int j = 6 * jj + c;
+                dst[(size_t)j * mg] = (0.0 - 0.0) / W.E[j * n - (j * (j - 1)) / 2];
+            }
+        } else {
+            transform_cols<MPC_QP_NB>(W, n, mg, H, nz, dst, jj, first, last, kind, kk, a, th);
+        }
+    }
+    for (; jj < H; ++jj) transform_cols<1>(W, n, mg, H, nz, dst, jj, first, last, kind, kk, a, th);
+    dst[(size_t)n * mg] = hval - th;
+}
+
 // Kraft's LSQ for the MPC shape.  W.E holds the packed LDL' factor l on entry ((n+1)n/2 + 1 entries; it is
 // overwritten), g: gradient, cvals: c(x), nz: structured dc/dx, lo / hi: bounds on the step (xl - x, xu - x).
 // Returns the mode (1 = solved) and writes the step s [n] and the multipliers y [m + 2n] (the bound rows'
@@ -439,79 +551,8 @@ SPMD_HD int lsq(const Team &T, const Work &W, int H, const double *g, const doub
         if (!(fabs(W.E[EO(j)]) >= 2.22e-16)) W.isc[8] = 0;
     T.sync();
     if (!W.isc[8]) return 5;
-    // ---- [g h] <- [g e^-1, h - g f]: one row per index, six columns at a time so that an earlier entry of the row
-    //      is read once per block; every sum still runs over k in ascending order.  Written to G and to AT.
-    PAR_FOR(T, i, 0, mg) {
-        int a = 0, first = H, last = -1, kind = 0, kk = 0;      // block range [first, last] holds the row's nonzeros
-        double hval;
-        if (i < m) {
-            const int st = i / 12, r = i % 12;
-            hval = -cvals[i];
-            if (r < 6) { a = r; kk = st; if (st >= 1) { first = 0; last = st - 1; kind = 1; } }        // position row
-            else { a = r - 6; if (st >= 1) { first = st - 1; last = st - 1; kind = 2; } }              // velocity row
-        } else if (i < m + n) {
-            const int v = i - m;
-            a = v % 6; first = v / 6; last = first; kind = 3; hval = lo[v];
-        } else {
-            const int v = i - m - n;
-            a = v % 6; first = v / 6; last = first; kind = 4; hval = -hi[v];
-        }
-        double *gi = W.G + i, *ai = W.AT + i;
-        const int kfirst = 6 * first;
-        double th = 0.0;
-        for (int jj = 0; jj < H; ++jj) {
-            const int jb = 6 * jj;
-            if (jj < first) {
-                for (int c = 0; c < 6; ++c) {
-                    const double res = (0.0 - 0.0) / W.E[EO(jb + c)];
-                    gi[(size_t)(jb + c) * mg] = res;
-                    ai[(size_t)(jb + c) * mg] = res;
-                }
-                continue;
-            }
-            double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0, a4 = 0.0, a5 = 0.0;
-            {
-                const double *er = W.E + jb;               // er[c] = e(k, jb + c), advanced row by row
-                for (int k = 0; k < jb; ++k) {
-                    if (k >= kfirst) {
-                        const double gk = ai[(size_t)k * mg];
-                        a0 = a0 + gk * er[0];
-                        a1 = a1 + gk * er[1];
-                        a2 = a2 + gk * er[2];
-                        a3 = a3 + gk * er[3];
-                        a4 = a4 + gk * er[4];
-                        a5 = a5 + gk * er[5];
-                    }
-                    er += n - k - 1;
-                }
-            }
-            double val = 0.0;
-            if (jj <= last) {
-                if (kind == 1) val = nz[6 * H + 6 * (jj * H - (jj * (jj - 1)) / 2 - jj - 1 + kk) + a];
-                else if (kind == 2) val = nz[6 * jj + a];
-                else val = (kind == 3) ? 1.0 : -1.0;
-            }
-            double gn[6], ac[6] = {a0, a1, a2, a3, a4, a5};
-#if defined(__HIPCC__)
-#pragma unroll
-#endif
-            for (int c = 0; c < 6; ++c) {
-                double t = ac[c];
-#if defined(__HIPCC__)
-#pragma unroll
-#endif
-                for (int c2 = 0; c2 < c; ++c2) t = t + gn[c2] * W.E[EO(jb + c2) + (c - c2)];
-                const double orig = (c == a && jj <= last) ? val : 0.0;
-                gn[c] = (orig - t) / W.E[EO(jb + c)];
-                gi[(size_t)(jb + c) * mg] = gn[c];
-                ai[(size_t)(jb + c) * mg] = gn[c];
-                th = th + gn[c] * W.ff[jb + c];
-            }
-        }
-        const double res = hval - th;
-        gi[(size_t)n * mg] = res;
-        ai[(size_t)n * mg] = res;
-    }
+    // ---- [g h] <- [g e^-1, h - g f], one row per index, into the matrix NNLS works on
+    PAR_FOR(T, i, 0, mg) transform_row(W, H, i, cvals, nz, lo, hi, W.AT + i);
     // ---- LDP: NNLS on the copy of [g h]^T with right-hand side e_{n+1}
     PAR_FOR(T, i, 0, n) W.bb[i] = 0.0;
     if (T.tid() == 0) W.bb[n] = 1.0;
@@ -522,13 +563,17 @@ SPMD_HD int lsq(const Team &T, const Work &W, int H, const double *g, const doub
     rnorm = W.sc[2];
     if (mode != 1) return mode;
     if (rnorm <= 0.0) return 4;
+    // ---- the rows of the transformed [g h] that are in the final set (NNLS overwrote its copy): computed again
+    PAR_FOR(T, i, 0, mg)
+        if (W.xn[i] != 0.0) transform_row(W, H, i, cvals, nz, lo, hi, W.G + i);
+    T.sync();
     // ---- column sums against the NNLS solution (column n is h): only the rows in the final set contribute
     PAR_FOR(T, j, 0, n + 1) {
         const double *gj = W.G + (size_t)j * mg;
         double t = 0.0;
         for (int i = 0; i < mg; ++i) {
             const double xi = W.xn[i];
-            if (xi != 0.0) t = t + gj[i] * xi;
+            if (xi != 0.0) t = t + gj[i] * xi;             // rows outside the set: not stored, not read
         }
         W.zz[j] = t;
     }
@@ -545,21 +590,27 @@ SPMD_HD int lsq(const Team &T, const Work &W, int H, const double *g, const doub
     PAR_FOR(T, j, 0, n) W.xs[j] = fac * W.zz[j];
     PAR_FOR(T, i, 0, mg) y[i] = 0.0 + fac * W.xn[i];
     T.sync();
-    // ---- back to the original variables: x = e^-1 (x + f), then the box (thread 0: a recurrence)
-    if (T.tid() == 0) {
-        for (int i = 0; i < n; ++i) W.xs[i] = W.xs[i] + 1.0 * W.ff[i];
-        for (int i = n - 1; i >= 0; --i) {
-            const double *er = W.E + EO(i) - i;            // er[j] = e(i, j)
+    // ---- back to the original variables: x = e^-1 (x + f) by back substitution, then the box.  Row i's sum runs
+    //      over j = i + 1, i + 2, ... while x(j) becomes known in the opposite order, so the sum itself is a serial
+    //      chain (thread 0); the products are formed by the team first.
+    PAR_FOR(T, i, 0, n) W.xs[i] = W.xs[i] + 1.0 * W.ff[i];
+    T.sync();
+    for (int i = n - 1; i >= 0; --i) {
+        const double *er = W.E + EO(i) - i;                // er[j] = e(i, j)
+        PAR_FOR(T, j, i + 1, n) W.piv[j] = er[j] * W.xs[j];
+        T.sync();
+        if (T.tid() == 0) {
             double t = 0.0;
-            for (int j = i + 1; j < n; ++j) t = t + er[j] * W.xs[j];
+            for (int j = i + 1; j < n; ++j) t = t + W.piv[j];
             W.xs[i] = (W.xs[i] - t) / er[i];
         }
-        for (int i = 0; i < n; ++i) {
-            double v = W.xs[i];
-            if (v < lo[i]) v = lo[i];
-            else if (v > hi[i]) v = hi[i];
-            s[i] = v;
-        }
+        T.sync();
+    }
+    PAR_FOR(T, i, 0, n) {
+        double v = W.xs[i];
+        if (v < lo[i]) v = lo[i];
+        else if (v > hi[i]) v = hi[i];
+        s[i] = v;
     }
     T.sync();
     return 1;
