@@ -106,6 +106,20 @@ SPMD_HD inline double nrm2(int n, const double *dx, int incx)
     return scale * sqrt(ssq);
 }
 
+// t + p[0] + p[1] + ... in that order; the loads of a block are issued together so that one thread does not wait
+// for each of them in turn
+SPMD_HD inline double sum_in_order(double t, const double *p, int count)
+{
+    int j = 0;
+    for (; j + 8 <= count; j += 8) {
+        const double p0 = p[j], p1 = p[j + 1], p2 = p[j + 2], p3 = p[j + 3], p4 = p[j + 4], p5 = p[j + 5], p6 = p[j + 6],
+                     p7 = p[j + 7];
+        t = t + p0; t = t + p1; t = t + p2; t = t + p3; t = t + p4; t = t + p5; t = t + p6; t = t + p7;
+    }
+    for (; j < count; ++j) t = t + p[j];
+    return t;
+}
+
 // NNLS on the transposed storage: entry (row r, column j) of Lawson & Hanson's a is AT[j + r*mg]
 // (1-based r in 1..mrow, j in 1..ncol).  b = W.bb, x = W.xn, w = W.wd, z = W.zz, index = W.idx.
 template <class Team>
@@ -147,16 +161,24 @@ SPMD_HD int nnls(const Team &T, const Work &W, int mrow, int ncol, int mg, doubl
                 W.redv[T.tid()] = best;
                 W.redi[T.tid()] = besti;
                 T.sync();
-                if (T.tid() == 0) {
-                    double wmax = 0.0;
-                    int izmax = 0;
-                    for (int q = 0; q < T.size(); ++q) {
+                // tree over the team's partial results: the larger value wins, the earlier position on a tie (what a
+                // scan from the left keeps), so the outcome does not depend on the team size
+                int width = 1;
+                while (width < T.size()) width *= 2;
+                for (int half = width / 2; half > 0; half /= 2) {
+                    const int q = T.tid() + half;
+                    if (T.tid() < half && q < T.size()) {
                         const double v = W.redv[q];
                         const int p = W.redi[q];
-                        if (p != 0 && (v > wmax || (v == wmax && p < izmax))) { wmax = v; izmax = p; }
+                        const double v0 = W.redv[T.tid()];
+                        const int p0 = W.redi[T.tid()];
+                        if (p != 0 && (p0 == 0 || v > v0 || (v == v0 && p < p0))) { W.redv[T.tid()] = v; W.redi[T.tid()] = p; }
                     }
-                    W.sc[0] = wmax;
-                    W.isc[0] = izmax;
+                    T.sync();
+                }
+                if (T.tid() == 0) {
+                    W.sc[0] = W.redi[0] != 0 ? W.redv[0] : 0.0;
+                    W.isc[0] = W.redi[0];
                 }
                 T.sync();
             }
@@ -600,8 +622,7 @@ SPMD_HD int lsq(const Team &T, const Work &W, int H, const double *g, const doub
         PAR_FOR(T, j, i + 1, n) W.piv[j] = er[j] * W.xs[j];
         T.sync();
         if (T.tid() == 0) {
-            double t = 0.0;
-            for (int j = i + 1; j < n; ++j) t = t + W.piv[j];
+            const double t = sum_in_order(0.0, W.piv + i + 1, n - i - 1);
             W.xs[i] = (W.xs[i] - t) / er[i];
         }
         T.sync();
