@@ -23,7 +23,7 @@ extern "C" {
 
 typedef struct mpc_slsqp_batch mpc_slsqp_batch;
 
-#define MPC_SLSQP_ABI_VERSION 1
+#define MPC_SLSQP_ABI_VERSION 2
 int mpc_slsqp_abi_version(void);
 
 /* threads <= 0: as many as OpenMP would use (OMP_NUM_THREADS).  Returns 0 or a negative code. */
@@ -73,6 +73,19 @@ double *mpc_slsqp_s(mpc_slsqp_batch *b);
 double *mpc_slsqp_r(mpc_slsqp_batch *b);
 int32_t *mpc_slsqp_qp_mode(mpc_slsqp_batch *b);
 const int32_t *mpc_slsqp_qp_flags(mpc_slsqp_batch *b);
+
+/* QP offload, staging.  One round's requests (the lists mpc_slsqp_advance_qp returned) move through two flat
+ * buffers of the caller's (pinned host memory, one copy each way), filled and emptied row by row on the batch's
+ * threads.  With nf / ng / nq requests for f and c / grad f / a QP:
+ *   pack    stage  = x[nf][n], x[ng][n] (clipped to the box: the points to evaluate), lo[nq][n], hi[nq][n], s[nq][n]
+ *           istage = want_f[nf], want_g[ng], want_q[nq], qp_flags[nq]
+ *   unpack  stage  = c[nf][m], grad f[ng][n], step[nq][n], multipliers[nq][m], f[nf]
+ *           istage = qp_mode[nq]   (step and multipliers are taken only where the mode is 1)
+ * Returns 0, or -1 for bad arguments. */
+int mpc_slsqp_pack(mpc_slsqp_batch *b, int nf, const int32_t *want_f, int ng, const int32_t *want_g, int nq,
+                   const int32_t *want_q, double *stage, int32_t *istage);
+int mpc_slsqp_unpack(mpc_slsqp_batch *b, int nf, const int32_t *want_f, int ng, const int32_t *want_g, int nq,
+                     const int32_t *want_q, const double *stage, const int32_t *istage);
 
 /* Seconds spent inside the core by the busiest thread / wall seconds of all rounds since mpc_slsqp_begin. */
 double mpc_slsqp_core_seconds(const mpc_slsqp_batch *b);

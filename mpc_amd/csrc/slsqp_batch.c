@@ -192,6 +192,71 @@ int mpc_slsqp_advance_qp(mpc_slsqp_batch *b, int32_t *want_f, int32_t *n_want_f,
     return nf + ng + nq;
 }
 
+int mpc_slsqp_pack(mpc_slsqp_batch *b, int nf, const int32_t *want_f, int ng, const int32_t *want_g, int nq,
+                   const int32_t *want_q, double *stage, int32_t *istage)
+{
+    if (!b || !b->offload || nf < 0 || ng < 0 || nq < 0 || !stage || !istage) return -1;
+    if ((nf && !want_f) || (ng && !want_g) || (nq && !want_q)) return -1;
+    const int n = b->n, n1 = b->n1;
+    const double *lb = b->lb, *ub = b->ub;
+    double *xf = stage, *xg = xf + (size_t)nf * n, *lo = xg + (size_t)ng * n, *hi = lo + (size_t)nq * n, *sv = hi + (size_t)nq * n;
+    int32_t *jf = istage, *jg = jf + nf, *jq = jg + ng, *fl = jq + nq;
+    const int rows = nf + ng + nq;
+#pragma omp parallel for schedule(static) num_threads(b->threads)
+    for (int k = 0; k < rows; ++k) {
+        if (k < nf + ng) {                                  /* the point to evaluate, inside the box (_clip_x_for_func) */
+            const int p = k < nf ? want_f[k] : want_g[k - nf];
+            const double *x = b->x + (size_t)p * n;
+            double *dst = k < nf ? xf + (size_t)k * n : xg + (size_t)(k - nf) * n;
+            for (int i = 0; i < n; ++i) {
+                double v = x[i];
+                v = v < lb[i] ? lb[i] : v;
+                v = v > ub[i] ? ub[i] : v;
+                dst[i] = v;
+            }
+            if (k < nf) jf[k] = p;
+            else jg[k - nf] = p;
+        } else {
+            const int q = k - nf - ng, p = want_q[q];
+            memcpy(lo + (size_t)q * n, b->u + (size_t)p * n1, sizeof(double) * n);
+            memcpy(hi + (size_t)q * n, b->v + (size_t)p * n1, sizeof(double) * n);
+            memcpy(sv + (size_t)q * n, b->s + (size_t)p * n1, sizeof(double) * n);
+            jq[q] = p;
+            fl[q] = b->qpflags[p];
+        }
+    }
+    return 0;
+}
+
+int mpc_slsqp_unpack(mpc_slsqp_batch *b, int nf, const int32_t *want_f, int ng, const int32_t *want_g, int nq,
+                     const int32_t *want_q, const double *stage, const int32_t *istage)
+{
+    if (!b || !b->offload || nf < 0 || ng < 0 || nq < 0 || !stage || !istage) return -1;
+    if ((nf && !want_f) || (ng && !want_g) || (nq && !want_q)) return -1;
+    const int n = b->n, m = b->m, n1 = b->n1;
+    const double *cv = stage, *gv = cv + (size_t)nf * m, *sv = gv + (size_t)ng * n, *rv = sv + (size_t)nq * n, *fv = rv + (size_t)nq * m;
+    const int rows = nf + ng + nq;
+#pragma omp parallel for schedule(static) num_threads(b->threads)
+    for (int k = 0; k < rows; ++k) {
+        if (k < nf) {
+            const int p = want_f[k];
+            b->f[p] = fv[k];
+            memcpy(b->c + (size_t)p * m, cv + (size_t)k * m, sizeof(double) * m);
+        } else if (k < nf + ng) {
+            const int q = k - nf, p = want_g[q];
+            memcpy(b->g + (size_t)p * n1, gv + (size_t)q * n, sizeof(double) * n);
+        } else {
+            const int q = k - nf - ng, p = want_q[q];
+            b->qpmode[p] = istage[q];
+            if (istage[q] == 1) {
+                memcpy(b->s + (size_t)p * n1, sv + (size_t)q * n, sizeof(double) * n);
+                memcpy(b->r + (size_t)p * b->r_len, rv + (size_t)q * m, sizeof(double) * m);
+            }
+        }
+    }
+    return 0;
+}
+
 int mpc_slsqp_advance(mpc_slsqp_batch *b, int32_t *want_f, int32_t *n_want_f, int32_t *want_g, int32_t *n_want_g)
 {
     if (!b || b->offload) return -1;

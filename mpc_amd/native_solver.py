@@ -21,7 +21,7 @@ from .solver import BatchSolveResult
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MPC_SLSQP_LIB") or os.path.join(_HERE, "libmpc_slsqp.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 _lib = None
 
 
@@ -63,6 +63,10 @@ def load():
         fn = getattr(L, f"mpc_slsqp_{name}")
         fn.restype = i32p
         fn.argtypes = [vp]
+    for name in ("pack", "unpack"):
+        fn = getattr(L, f"mpc_slsqp_{name}")
+        fn.restype = ip
+        fn.argtypes = [vp, ip, i32p, ip, i32p, ip, i32p, vp, vp]
     L.mpc_slsqp_core_seconds.restype = C.c_double
     L.mpc_slsqp_core_seconds.argtypes = [vp]
     if L.mpc_slsqp_abi_version() != ABI_VERSION:
@@ -320,48 +324,59 @@ class DeviceQpSLSQP:
         self._L = z(cap, (n + 1) * n // 2 + 1)
         self._G, self._C, self._NZ = z(cap, n), z(cap, m), z(cap, ctx.nz_count)
         self._R, self._V = z(cap, m + 2 * n), z(cap, n)
+        # staging, one copy each way per round (mpc_slsqp_pack / mpc_slsqp_unpack define the layouts)
+        pinned = lambda count, dt: torch.empty(count, dtype=dt).pin_memory()
+        self._in_h, self._in_d = pinned(cap * 3 * n, torch.float64), z(cap * 3 * n)
+        self._out_h, self._out_d = pinned(cap * (n + m + 1), torch.float64), z(cap * (n + m + 1))
+        self._iin_h, self._iin_d = pinned(2 * cap, torch.int32), torch.empty(2 * cap, dtype=torch.int32, device=dev)
+        self._iout_h, self._iout_d = pinned(cap, torch.int32), torch.empty(cap, dtype=torch.int32, device=dev)
         self._host_fallback = None
 
-    def _eval(self, sc, idx, need_grad):
+    def _round(self, sc, wf, wg, wq):
+        """Serve one round's requests: one staged copy in, the evaluations and the QP step, one staged copy out."""
         ctx, b, o = self.ctx, self.batch, self._out
-        K = len(idx)
-        self._x_dev[:K].copy_(torch.from_numpy(np.clip(b.X[idx], self.lb, self.ub)))       # _clip_x_for_func
-        idx_dev = torch.from_numpy(idx.astype(np.int32)).to(ctx.device)
-        sub = ctx.gather(sc, idx_dev, self._sub[sc.u_prev is not None])
-        rows = idx_dev.long()
-        if need_grad:
-            ctx.eval_fd_nz(sub, self._x_dev[:K], want_con=False,
-                           out=EvalResult(o.cost[:K], o.grad[:K], None, None, o.con_jac_nz[:K]))
-            self._G.index_copy_(0, rows, o.grad[:K])
-            self._NZ.index_copy_(0, rows, o.con_jac_nz[:K])
-            b.G[idx, :b.n] = o.grad[:K].cpu().numpy()
-        else:
-            ctx.eval(sub, self._x_dev[:K], out=EvalResult(o.cost[:K], None, o.con[:K], None))
-            self._C.index_copy_(0, rows, o.con[:K])
-            b.F[idx] = o.cost[:K].cpu().numpy()
-            b.Cc[idx] = o.con[:K].cpu().numpy()
-
-    def _qp(self, idx):
-        ctx, b = self.ctx, self.batch
         n, m = b.n, b.m
-        K = len(idx)
-        dev = ctx.device
-        up = lambda a, dt=torch.float64: torch.as_tensor(np.ascontiguousarray(a), dtype=dt).to(dev)
-        lo, hi, s_in = up(b.LO[idx, :n]), up(b.HI[idx, :n]), up(b.S[idx, :n])
-        index, flags = up(idx, torch.int32), up(b.QPFLAGS[idx], torch.int32)
-        s_out = torch.empty((K, n), dtype=torch.float64, device=dev)
-        r_out = torch.empty((K, m), dtype=torch.float64, device=dev)
-        mode = torch.zeros(K, dtype=torch.int32, device=dev)
-        from . import _ffi
-        _ffi.check(ctx._ctx, ctx._lib.mpc_qp_step(
-            ctx._ctx, K, self.cap, index.data_ptr(), flags.data_ptr(), lo.data_ptr(), hi.data_ptr(), s_in.data_ptr(),
-            self._L.data_ptr(), self._G.data_ptr(), self._C.data_ptr(), self._NZ.data_ptr(), self._R.data_ptr(),
-            self._V.data_ptr(), s_out.data_ptr(), r_out.data_ptr(), mode.data_ptr(), ctx._stream()))
-        md = mode.cpu().numpy()
-        ok = md == 1
-        b.S[idx[ok], :n] = s_out.cpu().numpy()[ok]
-        b.R[idx[ok], :m] = r_out.cpu().numpy()[ok]
-        b.QPMODE[idx] = md
+        nf, ng, nq = len(wf), len(wg), len(wq)
+        i32 = lambda a: a.ctypes.data_as(C.POINTER(C.c_int32))
+        lib = b._lib
+        if lib.mpc_slsqp_pack(b._b, nf, i32(wf), ng, i32(wg), nq, i32(wq), self._in_h.data_ptr(), self._iin_h.data_ptr()):
+            raise RuntimeError("mpc_slsqp_pack: bad arguments")
+        t_in, i_in = (nf + ng + 3 * nq) * n, nf + ng + 2 * nq
+        D, I, O = self._in_d, self._iin_d, self._out_d
+        D[:t_in].copy_(self._in_h[:t_in], non_blocking=True)
+        I[:i_in].copy_(self._iin_h[:i_in], non_blocking=True)
+        cut = lambda buf, start, rows, cols: buf[start:start + rows * cols].view(rows, cols)
+        xf, xg = cut(D, 0, nf, n), cut(D, nf * n, ng, n)
+        q0 = (nf + ng) * n
+        lo, hi, s_in = cut(D, q0, nq, n), cut(D, q0 + nq * n, nq, n), cut(D, q0 + 2 * nq * n, nq, n)
+        jf, jg, jq, fl = I[:nf], I[nf:nf + ng], I[nf + ng:nf + ng + nq], I[nf + ng + nq:i_in]
+        o_g = nf * m
+        o_s = o_g + ng * n
+        o_r = o_s + nq * n
+        o_f = o_r + nq * m
+        t_out = o_f + nf
+        c_out, g_out, s_out, r_out, f_out = cut(O, 0, nf, m), cut(O, o_g, ng, n), cut(O, o_s, nq, n), cut(O, o_r, nq, m), O[o_f:t_out]
+        subs = self._sub[sc.u_prev is not None]
+        if nf:
+            ctx.eval(ctx.gather(sc, jf, subs), xf, out=EvalResult(f_out, None, c_out, None))
+            self._C.index_copy_(0, jf.long(), c_out)
+        if ng:
+            ctx.eval_fd_nz(ctx.gather(sc, jg, subs), xg, want_con=False,
+                           out=EvalResult(o.cost[:ng], g_out, None, None, o.con_jac_nz[:ng]))
+            rows = jg.long()
+            self._G.index_copy_(0, rows, g_out)
+            self._NZ.index_copy_(0, rows, o.con_jac_nz[:ng])
+        if nq:
+            from . import _ffi
+            _ffi.check(ctx._ctx, ctx._lib.mpc_qp_step(
+                ctx._ctx, nq, self.cap, jq.data_ptr(), fl.data_ptr(), lo.data_ptr(), hi.data_ptr(), s_in.data_ptr(),
+                self._L.data_ptr(), self._G.data_ptr(), self._C.data_ptr(), self._NZ.data_ptr(), self._R.data_ptr(),
+                self._V.data_ptr(), s_out.data_ptr(), r_out.data_ptr(), self._iout_d.data_ptr(), ctx._stream()))
+            self._iout_h[:nq].copy_(self._iout_d[:nq], non_blocking=True)
+        self._out_h[:t_out].copy_(O[:t_out], non_blocking=True)
+        torch.cuda.current_stream(ctx.device).synchronize()
+        if lib.mpc_slsqp_unpack(b._b, nf, i32(wf), ng, i32(wg), nq, i32(wq), self._out_h.data_ptr(), self._iout_h.data_ptr()):
+            raise RuntimeError("mpc_slsqp_unpack: bad arguments")
 
     def solve(self, sc: ScenarioBatch, x0: np.ndarray) -> BatchSolveResult:
         ctx, b = self.ctx, self.batch
@@ -386,26 +401,18 @@ class DeviceQpSLSQP:
         b.G[:N, :n] = o.grad[:N].cpu().numpy()
         t_serve += time.perf_counter() - t0
         n_eval, n_eval_fd, n_qp, rounds = 0, N, 0, 0
-        t_qp = 0.0
+        t_qp = 0.0                  # the QP step is served inside the round: t_serve covers it
         while True:
-            want_f, want_g, want_q = (w.copy() for w in b.advance_qp())
+            want_f, want_g, want_q = b.advance_qp()
             rounds += 1
             if len(want_f) + len(want_g) + len(want_q) == 0:
                 break
             t0 = time.perf_counter()
-            if len(want_f):
-                self._eval(sc, want_f, False)
-                n_eval += len(want_f)
-            if len(want_g):
-                self._eval(sc, want_g, True)
-                n_eval_fd += len(want_g)
-            t1 = time.perf_counter()
-            if len(want_q):
-                self._qp(want_q)
-                n_qp += len(want_q)
-            t2 = time.perf_counter()
-            t_serve += t1 - t0
-            t_qp += t2 - t1
+            self._round(sc, want_f, want_g, want_q)
+            n_eval += len(want_f)
+            n_eval_fd += len(want_g)
+            n_qp += len(want_q)
+            t_serve += time.perf_counter() - t0
         x, fun = b.X[:N].copy(), b.F[:N].copy()
         nit, status = b.iterations[:N].astype(int), b.mode[:N].astype(int)
         redo = np.nonzero(status == MODE_NEEDS_HOST)[0]
