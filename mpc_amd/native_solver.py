@@ -294,24 +294,14 @@ class NativeBatchedSLSQP:
 MODE_NEEDS_HOST = 104      # slsqp_core.h: MPC_SLSQP_MODE_NEEDS_HOST
 
 
-class DeviceQpSLSQP:
-    """Batched SLSQP with the quadratic subproblems on the GPU.
+class _DeviceQpLane:
+    """One half of a DeviceQpSLSQP: its own batch in the C library, device state, staging buffers, context
+    (workspaces) and stream, so that two lanes can be in flight at once."""
 
-    The O(n^2)..O(n^3) linear algebra of every major iteration - the BFGS update of the LDL' factor and the QP
-    (``mpc_qp_step``: one workgroup per problem, arithmetic identical to the host core) - runs on the device,
-    where the factor, the derivatives and the multipliers of every problem stay resident; the host threads
-    keep the O(n + m) logic of the method (merit function, line search, convergence tests).  Per QP only the box,
-    the last step and the new step with its multipliers cross PCIe.  Results equal the host drivers' bit for bit.
-    A problem whose linearisation turns out inconsistent (Kraft's augmented problem) is solved again by the
-    host-only driver."""
-
-    def __init__(self, ctx: MpcContext, threads: int = 0, capacity: int = None):
-        if not ctx.nz_supported():
-            raise ValueError("the driver takes dc/dx in its structured form: the context needs MPC_ALGO_PREFIX")
+    def __init__(self, ctx: MpcContext, threads: int, capacity: int):
         self.ctx = ctx
         p = ctx.params
-        self.cap = cap = int(capacity or ctx.max_scenarios)
-        self.threads = threads
+        self.cap = cap = int(capacity)
         self.batch = NativeBatch(p.horizon, cap, threads, offload_qp=True)
         self.lb = np.array([b[0] for b in p.bounds()])
         self.ub = np.array([b[1] for b in p.bounds()])
@@ -330,7 +320,7 @@ class DeviceQpSLSQP:
         self._out_h, self._out_d = pinned(cap * (n + m + 1), torch.float64), z(cap * (n + m + 1))
         self._iin_h, self._iin_d = pinned(2 * cap, torch.int32), torch.empty(2 * cap, dtype=torch.int32, device=dev)
         self._iout_h, self._iout_d = pinned(cap, torch.int32), torch.empty(cap, dtype=torch.int32, device=dev)
-        self._host_fallback = None
+        self.stream = torch.cuda.Stream(device=dev)
 
     def _round(self, sc, wf, wg, wq):
         """Serve one round's requests: one staged copy in, the evaluations and the QP step, one staged copy out."""
@@ -379,7 +369,83 @@ class DeviceQpSLSQP:
             raise RuntimeError("mpc_slsqp_unpack: bad arguments")
 
     def solve(self, sc: ScenarioBatch, x0: np.ndarray) -> BatchSolveResult:
+        """All of this lane's problems (sc.count <= capacity), on the lane's stream; status MODE_NEEDS_HOST marks the
+        problems the caller has to solve again on the host."""
         ctx, b = self.ctx, self.batch
+        p = ctx.params
+        N, n = sc.count, p.n
+        with torch.cuda.stream(self.stream):
+            b.begin(x0, self.lb, self.ub, p.ftol, p.maxiter)
+            t0 = time.perf_counter()
+            o = self._out
+            self._x_dev[:N].copy_(torch.from_numpy(b.X[:N]))
+            ctx.eval_fd_nz(sc, self._x_dev[:N], out=EvalResult(o.cost[:N], o.grad[:N], o.con[:N], None, o.con_jac_nz[:N]))
+            self._G[:N].copy_(o.grad[:N])
+            self._C[:N].copy_(o.con[:N])
+            self._NZ[:N].copy_(o.con_jac_nz[:N])
+            b.F[:N] = o.cost[:N].cpu().numpy()
+            b.Cc[:N] = o.con[:N].cpu().numpy()
+            b.G[:N, :n] = o.grad[:N].cpu().numpy()
+            t_serve = time.perf_counter() - t0
+            n_eval, n_eval_fd, n_qp, rounds = 0, N, 0, 0
+            while True:
+                want_f, want_g, want_q = b.advance_qp()
+                rounds += 1
+                if len(want_f) + len(want_g) + len(want_q) == 0:
+                    break
+                t0 = time.perf_counter()
+                self._round(sc, want_f, want_g, want_q)
+                n_eval += len(want_f)
+                n_eval_fd += len(want_g)
+                n_qp += len(want_q)
+                t_serve += time.perf_counter() - t0
+        res = BatchSolveResult(x=b.X[:N].copy(), fun=b.F[:N].copy(), nit=b.iterations[:N].astype(int),
+                               status=b.mode[:N].astype(int), rounds=rounds, n_eval=n_eval, n_eval_fd=n_eval_fd,
+                               t_core=b.core_seconds, t_serve=t_serve)
+        res.n_qp = n_qp
+        return res
+
+    def close(self):
+        self.batch.close()
+
+
+class DeviceQpSLSQP:
+    """Batched SLSQP with the quadratic subproblems on the GPU.
+
+    The O(n^2)..O(n^3) linear algebra of every major iteration - the BFGS update of the LDL' factor and the QP
+    (``mpc_qp_step``: one workgroup per problem, arithmetic identical to the host core) - runs on the device,
+    where the factor, the derivatives and the multipliers of every problem stay resident; the host threads
+    keep the O(n + m) logic of the method (merit function, line search, convergence tests).  Per QP only the box,
+    the last step and the new step with its multipliers cross PCIe, staged into one copy each way per round.
+    ``lanes`` = 2 splits a batch into two halves, each with its own stream, context and host threads: while one
+    half's kernels run, the other half's host logic and copies proceed.  Results equal the host drivers' bit for
+    bit.  A problem whose linearisation turns out inconsistent (Kraft's augmented problem) is solved again by the
+    host-only driver."""
+
+    MIN_PER_LANE = 64          # below this a second lane only adds launches
+
+    def __init__(self, ctx: MpcContext, threads: int = 0, capacity: int = None, lanes: int = 2):
+        if not ctx.nz_supported():
+            raise ValueError("the driver takes dc/dx in its structured form: the context needs MPC_ALGO_PREFIX")
+        if lanes not in (1, 2):
+            raise ValueError("lanes must be 1 or 2")
+        self.ctx = ctx
+        self.cap = cap = int(capacity or ctx.max_scenarios)
+        self.threads = threads
+        if cap < 2 * self.MIN_PER_LANE:
+            lanes = 1
+        lane_cap = (cap + lanes - 1) // lanes
+        lane_threads = threads if lanes == 1 or threads <= 0 else max(1, (threads + 1) // 2)
+        self._ctxs = [ctx] + [MpcContext(ctx.params, lane_cap, ctx.device_index) for _ in range(lanes - 1)]
+        self.lanes = [_DeviceQpLane(c, lane_threads, lane_cap) for c in self._ctxs]
+        if lanes == 2:
+            from concurrent.futures import ThreadPoolExecutor
+
+            self._helper = ThreadPoolExecutor(max_workers=1)
+        self._host_fallback = None
+
+    def solve(self, sc: ScenarioBatch, x0: np.ndarray) -> BatchSolveResult:
+        ctx = self.ctx
         p = ctx.params
         N, n = sc.count, p.n
         if N > self.cap:
@@ -387,34 +453,25 @@ class DeviceQpSLSQP:
         if N == 0:
             return BatchSolveResult(np.zeros((0, n)), np.zeros(0), np.zeros(0, int), np.zeros(0, int), 0, 0, 0)
         x0 = np.asarray(x0, dtype=np.float64).reshape(N, n)
-        b.begin(x0, self.lb, self.ub, p.ftol, p.maxiter)
-        t_serve = 0.0
-        t0 = time.perf_counter()
-        o = self._out
-        self._x_dev[:N].copy_(torch.from_numpy(b.X[:N]))
-        ctx.eval_fd_nz(sc, self._x_dev[:N], out=EvalResult(o.cost[:N], o.grad[:N], o.con[:N], None, o.con_jac_nz[:N]))
-        self._G[:N].copy_(o.grad[:N])
-        self._C[:N].copy_(o.con[:N])
-        self._NZ[:N].copy_(o.con_jac_nz[:N])
-        b.F[:N] = o.cost[:N].cpu().numpy()
-        b.Cc[:N] = o.con[:N].cpu().numpy()
-        b.G[:N, :n] = o.grad[:N].cpu().numpy()
-        t_serve += time.perf_counter() - t0
-        n_eval, n_eval_fd, n_qp, rounds = 0, N, 0, 0
-        t_qp = 0.0                  # the QP step is served inside the round: t_serve covers it
-        while True:
-            want_f, want_g, want_q = b.advance_qp()
-            rounds += 1
-            if len(want_f) + len(want_g) + len(want_q) == 0:
-                break
-            t0 = time.perf_counter()
-            self._round(sc, want_f, want_g, want_q)
-            n_eval += len(want_f)
-            n_eval_fd += len(want_g)
-            n_qp += len(want_q)
-            t_serve += time.perf_counter() - t0
-        x, fun = b.X[:N].copy(), b.F[:N].copy()
-        nit, status = b.iterations[:N].astype(int), b.mode[:N].astype(int)
+        t_start = time.perf_counter()
+        caller = torch.cuda.current_stream(ctx.device)
+        for lane in self.lanes:
+            lane.stream.wait_stream(caller)              # the scenarios were written on the caller's stream
+        if len(self.lanes) == 1 or (N < 2 * self.MIN_PER_LANE and N <= self.lanes[0].cap):
+            parts, cuts = [self.lanes[0].solve(sc, x0)], [0, N]
+        else:
+            half = (N + 1) // 2
+            other = self._helper.submit(self.lanes[1].solve, sc.slice(half, N), x0[half:])
+            try:
+                first = self.lanes[0].solve(sc.slice(0, half), x0[:half])
+            finally:
+                second = other.result()
+            parts, cuts = [first, second], [0, half, N]
+        x = np.concatenate([r.x for r in parts])
+        fun = np.concatenate([r.fun for r in parts])
+        nit = np.concatenate([r.nit for r in parts])
+        status = np.concatenate([r.status for r in parts])
+        n_eval, n_eval_fd = sum(r.n_eval for r in parts), sum(r.n_eval_fd for r in parts)
         redo = np.nonzero(status == MODE_NEEDS_HOST)[0]
         if len(redo):                       # inconsistent linearisation somewhere along the way: host-only solve
             if self._host_fallback is None:
@@ -425,15 +482,21 @@ class DeviceQpSLSQP:
             x[redo], fun[redo], nit[redo], status[redo] = r2.x, r2.fun, r2.nit, r2.status
             n_eval += r2.n_eval
             n_eval_fd += r2.n_eval_fd
-        res = BatchSolveResult(x=x, fun=fun, nit=nit, status=status, rounds=rounds, n_eval=n_eval, n_eval_fd=n_eval_fd,
-                               t_core=b.core_seconds, t_serve=t_serve)
-        res.n_qp, res.t_qp, res.n_host_fallback = n_qp, t_qp, len(redo)
+        res = BatchSolveResult(x=x, fun=fun, nit=nit, status=status, rounds=max(r.rounds for r in parts), n_eval=n_eval,
+                               n_eval_fd=n_eval_fd, t_core=max(r.t_core for r in parts), t_serve=max(r.t_serve for r in parts))
+        res.n_qp, res.t_qp, res.n_host_fallback = sum(r.n_qp for r in parts), 0.0, len(redo)
+        res.t_wall = time.perf_counter() - t_start
         return res
 
     def close(self):
-        self.batch.close()
+        for lane in self.lanes:
+            lane.close()
+        if getattr(self, "_helper", None) is not None:
+            self._helper.shutdown()
+            self._helper = None
         if self._host_fallback is not None:
             self._host_fallback.close()
+            self._host_fallback = None
 
     def __enter__(self):
         return self
