@@ -22,23 +22,30 @@ extern __shared__ double qp_lds[];
 
 // The team's workspace: the two matrices in its slice of global memory, the packed triangle and the vectors in
 // LDS when the launch gave it room for them (lds != 0), else in the same slice.
-__device__ lsqspmd::Work team_work(double *work, int *iwork, size_t wd, size_t wi, int n, int m, int lds)
+// (A template parameter, not a run-time switch: with one origin per pointer the compiler addresses the small pool
+// with LDS instructions instead of flat ones.)
+template <bool kLds>
+__device__ lsqspmd::Work team_work(double *work, int *iwork, size_t wd, size_t wi, int n, int m)
 {
     double *big = work + (size_t)blockIdx.x * wd;
-    if (!lds) return lsqspmd::carve(big, big + lsqspmd::big_doubles(n, m), iwork + (size_t)blockIdx.x * wi, n, m, (int)blockDim.x);
-    double *small = qp_lds;
-    return lsqspmd::carve(big, small, reinterpret_cast<int *>(small + lsqspmd::small_doubles(n, m, (int)blockDim.x)), n, m,
-                          (int)blockDim.x);
+    if constexpr (!kLds) {
+        return lsqspmd::carve(big, big + lsqspmd::big_doubles(n, m), iwork + (size_t)blockIdx.x * wi, n, m, (int)blockDim.x);
+    } else {
+        double *small = qp_lds;
+        return lsqspmd::carve(big, small, reinterpret_cast<int *>(small + lsqspmd::small_doubles(n, m, (int)blockDim.x)), n, m,
+                              (int)blockDim.x);
+    }
 }
 
+template <bool kLds>
 __global__ void __launch_bounds__(mpck::kQpThreads, MPC_QP_WAVES)
 qp_kernel(int H, int count, const double *__restrict__ l, const double *__restrict__ g, const double *__restrict__ c,
           const double *__restrict__ nz, const double *__restrict__ lo, const double *__restrict__ hi, double *__restrict__ s,
-          double *__restrict__ y, int32_t *__restrict__ mode, double *work, int *iwork, size_t wd, size_t wi, int lds)
+          double *__restrict__ y, int32_t *__restrict__ mode, double *work, int *iwork, size_t wd, size_t wi)
 {
     const int n = 6 * H, m = 12 * (H + 1), mg = m + 2 * n, nzc = 6 * H + 3 * H * (H + 1);
     const int ldl = (n + 1) * n / 2 + 1;
-    const lsqspmd::Work W = team_work(work, iwork, wd, wi, n, m, lds);
+    const lsqspmd::Work W = team_work<kLds>(work, iwork, wd, wi, n, m);
     const HipTeam T;
     for (int p = (int)blockIdx.x; p < count; p += (int)gridDim.x) {
         const double *lp = l + (size_t)p * ldl;
@@ -56,16 +63,17 @@ qp_kernel(int H, int count, const double *__restrict__ l, const double *__restri
 // Lagrangian gradient v = g - (dc/dx)^T r for the next update.  State rows are addressed by problem, the
 // request's own arrays by position in the list.  The factor is staged in the team's triangle (W.E), updated
 // there, written back, and then turned in place into the QP's e.
+template <bool kLds>
 __global__ void __launch_bounds__(mpck::kQpThreads, MPC_QP_WAVES)
 qp_step_kernel(int H, int count, const int32_t *__restrict__ index, const int32_t *__restrict__ flags,
                const double *__restrict__ lo, const double *__restrict__ hi, const double *__restrict__ s_in, double *L,
                const double *__restrict__ G, const double *__restrict__ C, const double *__restrict__ NZ, double *R, double *V,
                double *__restrict__ s_out, double *__restrict__ r_out, int32_t *__restrict__ mode, double *work, int *iwork,
-               size_t wd, size_t wi, int lds)
+               size_t wd, size_t wi)
 {
     const int n = 6 * H, m = 12 * (H + 1), mg = m + 2 * n, nzc = 6 * H + 3 * H * (H + 1);
     const int ldl = (n + 1) * n / 2 + 1;
-    const lsqspmd::Work W = team_work(work, iwork, wd, wi, n, m, lds);
+    const lsqspmd::Work W = team_work<kLds>(work, iwork, wd, wi, n, m);
     const HipTeam T;
     for (int k = (int)blockIdx.x; k < count; k += (int)gridDim.x) {
         const size_t p = (size_t)index[k];
@@ -137,11 +145,15 @@ hipError_t launch_qp_step(int H, int count, int teams, const int32_t *index, con
 {
     const size_t lds = lds_bytes(H);
     if (lds) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(qp_step_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(qp_step_kernel<true>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(qp_step_kernel<true>, dim3((unsigned)teams), dim3(kQpThreads), lds, stream, H, count, index, flags, lo,
+                           hi, s_in, L, G, C, NZ, R, V, s_out, r_out, mode, work, iwork, qp_work_doubles(H), qp_work_ints(H));
+    } else {
+        hipLaunchKernelGGL(qp_step_kernel<false>, dim3((unsigned)teams), dim3(kQpThreads), 0, stream, H, count, index, flags, lo,
+                           hi, s_in, L, G, C, NZ, R, V, s_out, r_out, mode, work, iwork, qp_work_doubles(H), qp_work_ints(H));
     }
-    hipLaunchKernelGGL(qp_step_kernel, dim3((unsigned)teams), dim3(kQpThreads), lds, stream, H, count, index, flags, lo, hi, s_in,
-                       L, G, C, NZ, R, V, s_out, r_out, mode, work, iwork, qp_work_doubles(H), qp_work_ints(H), lds ? 1 : 0);
     return hipGetLastError();
 }
 
@@ -154,11 +166,15 @@ hipError_t launch_qp(int H, int count, int teams, const double *l, const double 
 {
     const size_t lds = lds_bytes(H);
     if (lds) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(qp_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(qp_kernel<true>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(qp_kernel<true>, dim3((unsigned)teams), dim3(kQpThreads), lds, stream, H, count, l, g, c, nz, lo, hi, s,
+                           y, mode, work, iwork, qp_work_doubles(H), qp_work_ints(H));
+    } else {
+        hipLaunchKernelGGL(qp_kernel<false>, dim3((unsigned)teams), dim3(kQpThreads), 0, stream, H, count, l, g, c, nz, lo, hi, s,
+                           y, mode, work, iwork, qp_work_doubles(H), qp_work_ints(H));
     }
-    hipLaunchKernelGGL(qp_kernel, dim3((unsigned)teams), dim3(kQpThreads), lds, stream, H, count, l, g, c, nz, lo, hi, s, y, mode,
-                       work, iwork, qp_work_doubles(H), qp_work_ints(H), lds ? 1 : 0);
     return hipGetLastError();
 }
 

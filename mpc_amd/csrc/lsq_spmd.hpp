@@ -383,39 +383,77 @@ SPMD_HD int nnls(const Team &T, const Work &W, int mrow, int ncol, int mg, doubl
 #undef AT
 }
 
-// Row i of [g h] <- [g e^-1, h - g f] for the MPC's constraint matrix, written to dst[j * mg], j = 0..n (entry n is
-// h).  The row is generated from the structured Jacobian / the bounds; columns are taken NB * 6 at a time so that an
-// earlier entry of the row is read back once per block, and every sum runs over k in ascending order as in the
-// serial text.  Terms before the row's first nonzero are left out (they add +-0.0 to a sum that is +0.0).
-template <int NB>
-SPMD_HD inline void transform_cols(const Work &W, int n, int mg, int H, const double *nz, double *dst, int jj0, int first,
-                                   int last, int kind, int kk, int a, double &th)
+// Rows of [g h] <- [g e^-1, h - g f] for the MPC's constraint matrix, R rows per call, each written to
+// dst[r][j * mg], j = 0..n (entry n is h).  A row is generated from the structured Jacobian / the bounds; columns are
+// taken NB * 6 at a time so that an earlier entry of the row is read back once per block, the R rows share every read
+// of e, and every sum runs over k in ascending order as in the serial text.  Blocks of earlier columns in which none
+// of the R rows has a nonzero yet are left out of the sums: their entries are +-0.0, and +-0.0 * e added to a sum
+// that is +0.0 (or to any nonzero sum) changes nothing.
+#if defined(__HIPCC__)
+#define SPMD_UNROLL _Pragma("unroll")
+#else
+#define SPMD_UNROLL
+#endif
+#ifndef MPC_QP_NB
+#define MPC_QP_NB 2
+#endif
+
+struct RowDesc {
+    int a, first, last, kind, kk;      // sub-blocks [first, last] hold the row's nonzeros, in column 6 * jj + a of each
+    double hval;
+};
+
+SPMD_HD inline RowDesc describe_row(int H, int i, const double *cvals, const double *lo, const double *hi)
+{
+    const int n = 6 * H, m = 12 * (H + 1);
+    RowDesc d;
+    d.a = 0; d.first = H; d.last = -1; d.kind = 0; d.kk = 0;
+    if (i < m) {
+        const int st = i / 12, r = i % 12;
+        d.hval = -cvals[i];
+        if (r < 6) { d.a = r; d.kk = st; if (st >= 1) { d.first = 0; d.last = st - 1; d.kind = 1; } }        // position row
+        else { d.a = r - 6; if (st >= 1) { d.first = st - 1; d.last = st - 1; d.kind = 2; } }                // velocity row
+    } else if (i < m + n) {
+        const int v = i - m;
+        d.a = v % 6; d.first = v / 6; d.last = d.first; d.kind = 3; d.hval = lo[v];
+    } else {
+        const int v = i - m - n;
+        d.a = v % 6; d.first = v / 6; d.last = d.first; d.kind = 4; d.hval = -hi[v];
+    }
+    return d;
+}
+
+template <int NB, int R>
+SPMD_HD inline void transform_cols(const Work &W, int n, int mg, int H, const double *nz, double *const *dst, int jj0,
+                                   const RowDesc *d, int first_any, double *th)
 {
     constexpr int NC = 6 * NB;
     const int jb = 6 * jj0;
 #define EO(r) ((r) * n - ((r) * ((r) - 1)) / 2)
-    double acc[NC];
-#if defined(__HIPCC__)
-#pragma unroll
-#endif
-    for (int c = 0; c < NC; ++c) acc[c] = 0.0;
+    double acc[R][NC];
+    SPMD_UNROLL
+    for (int r = 0; r < R; ++r) {
+        SPMD_UNROLL
+        for (int c = 0; c < NC; ++c) acc[r][c] = 0.0;
+    }
     {
         const double *er = W.E + jb;                       // er[c] = e(k, jb + c), advanced row by row
         for (int kb = 0; kb < jj0; ++kb) {
-            if (kb >= first) {
-                double gk[6];
-#if defined(__HIPCC__)
-#pragma unroll
-#endif
-                for (int q = 0; q < 6; ++q) gk[q] = dst[(size_t)(6 * kb + q) * mg];
-#if defined(__HIPCC__)
-#pragma unroll
-#endif
+            if (kb >= first_any) {
+                double gk[R][6];
+                SPMD_UNROLL
+                for (int r = 0; r < R; ++r) {
+                    SPMD_UNROLL
+                    for (int q = 0; q < 6; ++q) gk[r][q] = dst[r][(size_t)(6 * kb + q) * mg];
+                }
+                SPMD_UNROLL
                 for (int q = 0; q < 6; ++q) {
-#if defined(__HIPCC__)
-#pragma unroll
-#endif
-                    for (int c = 0; c < NC; ++c) acc[c] = acc[c] + gk[q] * er[c];
+                    SPMD_UNROLL
+                    for (int c = 0; c < NC; ++c) {
+                        const double e = er[c];
+                        SPMD_UNROLL
+                        for (int r = 0; r < R; ++r) acc[r][c] = acc[r][c] + gk[r][q] * e;
+                    }
                     er += n - (6 * kb + q) - 1;
                 }
             } else {
@@ -423,72 +461,75 @@ SPMD_HD inline void transform_cols(const Work &W, int n, int mg, int H, const do
             }
         }
     }
-    double val[NB];
-#if defined(__HIPCC__)
-#pragma unroll
-#endif
-    for (int b = 0; b < NB; ++b) {
-        const int jj = jj0 + b;
-        val[b] = 0.0;
-        if (jj >= first && jj <= last) {
-            if (kind == 1) val[b] = nz[6 * H + 6 * (jj * H - (jj * (jj - 1)) / 2 - jj - 1 + kk) + a];
-            else if (kind == 2) val[b] = nz[6 * jj + a];
-            else val[b] = (kind == 3) ? 1.0 : -1.0;
+    double val[R][NB];
+    SPMD_UNROLL
+    for (int r = 0; r < R; ++r) {
+        SPMD_UNROLL
+        for (int b = 0; b < NB; ++b) {
+            const int jj = jj0 + b;
+            double v = 0.0;
+            if (jj >= d[r].first && jj <= d[r].last) {
+                if (d[r].kind == 1) v = nz[6 * H + 6 * (jj * H - (jj * (jj - 1)) / 2 - jj - 1 + d[r].kk) + d[r].a];
+                else if (d[r].kind == 2) v = nz[6 * jj + d[r].a];
+                else v = (d[r].kind == 3) ? 1.0 : -1.0;
+            }
+            val[r][b] = v;
         }
     }
-#if defined(__HIPCC__)
-#pragma unroll
-#endif
+    SPMD_UNROLL
     for (int c = 0; c < NC; ++c) {
-        double t = acc[c];
-#if defined(__HIPCC__)
-#pragma unroll
-#endif
-        for (int c2 = 0; c2 < c; ++c2) t = t + acc[c2] * W.E[EO(jb + c2) + (c - c2)];   // acc[c2] holds the new g(i, jb + c2)
-        const double orig = (c % 6 == a) ? val[c / 6] : 0.0;
-        const double gn = (orig - t) / W.E[EO(jb + c)];
-        acc[c] = gn;
-        dst[(size_t)(jb + c) * mg] = gn;
-        th = th + gn * W.ff[jb + c];
+        double t[R];
+        SPMD_UNROLL
+        for (int r = 0; r < R; ++r) t[r] = acc[r][c];
+        SPMD_UNROLL
+        for (int c2 = 0; c2 < c; ++c2) {
+            const double e = W.E[EO(jb + c2) + (c - c2)];
+            SPMD_UNROLL
+            for (int r = 0; r < R; ++r) t[r] = t[r] + acc[r][c2] * e;      // acc[r][c2] holds the new g(i_r, jb + c2)
+        }
+        const double diag = W.E[EO(jb + c)], fj = W.ff[jb + c];
+        SPMD_UNROLL
+        for (int r = 0; r < R; ++r) {
+            const double orig = (c % 6 == d[r].a) ? val[r][c / 6] : 0.0;
+            const double gn = (orig - t[r]) / diag;
+            acc[r][c] = gn;
+            dst[r][(size_t)(jb + c) * mg] = gn;
+            th[r] = th[r] + gn * fj;
+        }
     }
 #undef EO
 }
 
-SPMD_HD inline void transform_row(const Work &W, int H, int i, const double *cvals, const double *nz, const double *lo,
-                                  const double *hi, double *dst)
+template <int R>
+SPMD_HD inline void transform_rows(const Work &W, int H, const int *rows, const double *cvals, const double *nz,
+                                   const double *lo, const double *hi, double *const *dst)
 {
-    const int n = 6 * H, m = 12 * (H + 1), mg = m + 2 * n;
-    int a = 0, first = H, last = -1, kind = 0, kk = 0;      // sub-blocks [first, last] hold the row's nonzeros
-    double hval;
-    if (i < m) {
-        const int st = i / 12, r = i % 12;
-        hval = -cvals[i];
-        if (r < 6) { a = r; kk = st; if (st >= 1) { first = 0; last = st - 1; kind = 1; } }        // position row
-        else { a = r - 6; if (st >= 1) { first = st - 1; last = st - 1; kind = 2; } }              // velocity row
-    } else if (i < m + n) {
-        const int v = i - m;
-        a = v % 6; first = v / 6; last = first; kind = 3; hval = lo[v];
-    } else {
-        const int v = i - m - n;
-        a = v % 6; first = v / 6; last = first; kind = 4; hval = -hi[v];
+    const int n = 6 * H, mg = 12 * (H + 1) + 2 * n;
+    RowDesc d[R];
+    double th[R];
+    int first_any = H;
+    SPMD_UNROLL
+    for (int r = 0; r < R; ++r) {
+        d[r] = describe_row(H, rows[r], cvals, lo, hi);
+        th[r] = 0.0;
+        first_any = d[r].first < first_any ? d[r].first : first_any;
     }
-    double th = 0.0;
     int jj = 0;
-#ifndef MPC_QP_NB
-#define MPC_QP_NB 4
-#endif
     for (; jj + MPC_QP_NB <= H; jj += MPC_QP_NB) {
-        if (jj + MPC_QP_NB <= first) {                      // all zeros so far: (0 - 0) / e(j, j)
+        if (jj + MPC_QP_NB <= first_any) {                  // all zeros so far: (0 - 0) / e(j, j)
             for (int c = 0; c < 6 * MPC_QP_NB; ++c) {
                 const int j = 6 * jj + c;
-                dst[(size_t)j * mg] = (0.0 - 0.0) / W.E[j * n - (j * (j - 1)) / 2];
+                const double res = (0.0 - 0.0) / W.E[j * n - (j * (j - 1)) / 2];
+                SPMD_UNROLL
+                for (int r = 0; r < R; ++r) dst[r][(size_t)j * mg] = res;
             }
         } else {
-            transform_cols<MPC_QP_NB>(W, n, mg, H, nz, dst, jj, first, last, kind, kk, a, th);
+            transform_cols<MPC_QP_NB, R>(W, n, mg, H, nz, dst, jj, d, first_any, th);
         }
     }
-    for (; jj < H; ++jj) transform_cols<1>(W, n, mg, H, nz, dst, jj, first, last, kind, kk, a, th);
-    dst[(size_t)n * mg] = hval - th;
+    for (; jj < H; ++jj) transform_cols<1, R>(W, n, mg, H, nz, dst, jj, d, first_any, th);
+    SPMD_UNROLL
+    for (int r = 0; r < R; ++r) dst[r][(size_t)n * mg] = d[r].hval - th[r];
 }
 
 // Kraft's LSQ for the MPC shape.  W.E holds the packed LDL' factor l on entry ((n+1)n/2 + 1 entries; it is
@@ -574,7 +615,12 @@ SPMD_HD int lsq(const Team &T, const Work &W, int H, const double *g, const doub
     T.sync();
     if (!W.isc[8]) return 5;
     // ---- [g h] <- [g e^-1, h - g f], one row per index, into the matrix NNLS works on
-    PAR_FOR(T, i, 0, mg) transform_row(W, H, i, cvals, nz, lo, hi, W.AT + i);
+    //      (two rows per index, half the matrix apart: they share the reads of e)
+    PAR_FOR(T, i, 0, mg / 2) {
+        const int rows[2] = {i, i + mg / 2};
+        double *const dst[2] = {W.AT + i, W.AT + i + mg / 2};
+        transform_rows<2>(W, H, rows, cvals, nz, lo, hi, dst);
+    }
     // ---- LDP: NNLS on the copy of [g h]^T with right-hand side e_{n+1}
     PAR_FOR(T, i, 0, n) W.bb[i] = 0.0;
     if (T.tid() == 0) W.bb[n] = 1.0;
@@ -587,7 +633,11 @@ SPMD_HD int lsq(const Team &T, const Work &W, int H, const double *g, const doub
     if (rnorm <= 0.0) return 4;
     // ---- the rows of the transformed [g h] that are in the final set (NNLS overwrote its copy): computed again
     PAR_FOR(T, i, 0, mg)
-        if (W.xn[i] != 0.0) transform_row(W, H, i, cvals, nz, lo, hi, W.G + i);
+        if (W.xn[i] != 0.0) {
+            const int rows[1] = {i};
+            double *const dst[1] = {W.G + i};
+            transform_rows<1>(W, H, rows, cvals, nz, lo, hi, dst);
+        }
     T.sync();
     // ---- column sums against the NNLS solution (column n is h): only the rows in the final set contribute
     PAR_FOR(T, j, 0, n + 1) {

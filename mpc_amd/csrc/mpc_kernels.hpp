@@ -54,7 +54,10 @@ hipError_t launch_prepare_tick(const mpc_params &P, int N, const double (&dyn)[6
 
 // SLSQP's QP subproblem, one workgroup per problem (kernels_qp.hip).  `teams` workgroups share the batch;
 // work / iwork hold teams * qp_work_doubles(H) doubles / teams * qp_work_ints(H) ints.
-constexpr int kQpThreads = 512;
+#ifndef MPC_QP_THREADS
+#define MPC_QP_THREADS 512
+#endif
+constexpr int kQpThreads = MPC_QP_THREADS;
 constexpr size_t kQpLdsLimit = 160 * 1024;   // LDS of one CU (gfx950)
 int qp_teams_per_cu(int H);                  // resident teams per CU the QP kernels are sized for
 size_t qp_work_doubles(int H);
