@@ -184,14 +184,15 @@ def single_tick_latency(device, with_cpu):
     return out
 
 
-def solve_rate(ctx, mp, per_thread, threads, rank, world, dist):
+def solve_rate(ctx, mp, sample, threads, rank, world, dist, device_qp=True):
     """MPC solves/s on a bounded sample (BASELINE.json's second metric): full SLSQP solves of
-    angular-motion scenarios (configs[2] shape), one tick each.  Evaluations run on the GPU; the
-    quadratic subproblems run in the native host driver (libmpc_slsqp.so: C restatement of scipy's SLSQP
-    core, bit-identical iterates) on `threads` host threads per GPU, so this rate is host-bound and
-    scales with host cores, not with the GPU.  Every rank calls this; a rank that fails reports it and
-    all ranks skip together (no hang)."""
-    from mpc_amd.native_solver import NativeBatchedSLSQP
+    angular-motion scenarios (configs[2] shape), one tick each.  device_qp: evaluations, the BFGS update and
+    the quadratic subproblem of every major iteration run on the GPU (mpc_qp_step), the O(n + m) logic of
+    the method in libmpc_slsqp.so on `threads` host threads per GPU (DeviceQpSLSQP).  Otherwise the whole
+    SLSQP core runs on the host threads (NativeBatchedSLSQP) and only the evaluations on the GPU: that rate
+    is host-bound.  Iterates are bit-identical either way.  Every rank calls this; a rank that fails
+    reports it and all ranks skip together (no hang)."""
+    from mpc_amd.native_solver import DeviceQpSLSQP, NativeBatchedSLSQP
     from mpc_amd.solver import BatchedMPC
 
     def all_ok(ok):
@@ -201,13 +202,13 @@ def solve_rate(ctx, mp, per_thread, threads, rank, world, dist):
         all_reduce(dist, t, dist.ReduceOp.MIN)       # doubles as the barrier before the timed part
         return bool(t.item() > 0.5)
 
-    count = min(per_thread * threads, ctx.max_scenarios)
+    count = min(sample, ctx.max_scenarios)
     native, err, hs, bm, dt = None, None, None, None, 0.0
     try:
         hs = make_scenarios(mp, DeviceKinematics(ctx), count, motion="angular", cfg_id=3, goal_jitter=0.0,
                             first=rank * count)
-        native = NativeBatchedSLSQP(ctx, threads=threads, capacity=count)
-        log("native solver up")
+        native = (DeviceQpSLSQP if device_qp else NativeBatchedSLSQP)(ctx, threads=threads, capacity=count)
+        log("solver up")
         warm = min(count, 2 * threads)
         BatchedMPC(ctx, solver=native).compute_control(hs.q0[:warm], hs.state0[:warm, 12:18], hs.target[:warm], hs.base[:warm])
         torch.cuda.synchronize()
@@ -238,12 +239,19 @@ def solve_rate(ctx, mp, per_thread, threads, rank, world, dist):
         all_reduce(dist, stats, dist.ReduceOp.SUM)
         stats[0] = mx[0]
     dt_all, solved, conv, nfd, nf = (float(v) for v in stats.tolist())
-    return {"value": solved / dt_all, "unit": "solves/s", "host_bound": True, "host_threads_per_gpu": threads,
-            "sample": f"{int(solved)} angular-motion scenarios ({count} per GPU), H={mp.horizon}, one tick each, "
-                      f"{int(conv)} converged, {int(nfd)} eval_fd + {int(nf)} eval scenario-evals on the GPU, SLSQP cores "
-                      f"(libmpc_slsqp.so) on {threads} host threads per GPU",
-            "seconds": dt_all, "mean_iterations": float(r.nit.mean()), "rounds_rank0": r.rounds,
-            "rank0_core_seconds_busiest_thread": r.t_core, "rank0_seconds_serving_from_gpu": r.t_serve}
+    where = ("BFGS updates and QP subproblems on the GPU (mpc_qp_step), SLSQP's scalar logic" if device_qp
+             else "SLSQP cores")
+    out = {"value": solved / dt_all, "unit": "solves/s", "driver": "DeviceQpSLSQP" if device_qp else "NativeBatchedSLSQP",
+           "host_bound": not device_qp, "host_threads_per_gpu": threads,
+           "sample": f"{int(solved)} angular-motion scenarios ({count} per GPU), H={mp.horizon}, one tick each, "
+                     f"{int(conv)} converged, {int(nfd)} eval_fd + {int(nf)} eval scenario-evals on the GPU, {where} "
+                     f"(libmpc_slsqp.so) on {threads} host threads per GPU",
+           "seconds": dt_all, "mean_iterations": float(r.nit.mean()), "rounds_rank0": r.rounds,
+           "rank0_core_seconds_busiest_thread": r.t_core, "rank0_seconds_serving_from_gpu": r.t_serve}
+    if device_qp:
+        out["rank0_qp_subproblems_on_gpu"] = int(r.n_qp)
+        out["rank0_solved_again_on_host"] = int(r.n_host_fallback)
+    return out
 
 
 def pool_solve_rate(ctx, mp, per_worker, workers):
@@ -273,8 +281,8 @@ def main():
     ap.add_argument("--motion", default="linear", choices=["linear", "angular"])
     ap.add_argument("--algo", type=int, default=_ffi.ALGO_AUTO)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--solve-sample", type=int, default=256,
-                    help="scenarios per host thread in the bounded solves/s sample (0: skip)")
+    ap.add_argument("--solve-sample", type=int, default=16384,
+                    help="scenarios per GPU in the bounded solves/s sample (0: skip)")
     ap.add_argument("--solve-workers", type=int, default=0, help="SLSQP host threads per GPU (0: host cores - 1)")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="development only: every rank uses device 0 and the process group is gloo, to walk the "
@@ -432,6 +440,11 @@ def main():
         if solves is not None:
             line["solves"] = solves
             if extras and world == 1 and "error" not in solves:
+                try:        # the host-only driver on a smaller sample: what the GPU-side QP buys
+                    line["solves_host_core"] = solve_rate(ctx, mp, 256 * solves["host_threads_per_gpu"],
+                                                          solves["host_threads_per_gpu"], 0, 1, None, device_qp=False)
+                except Exception as exc:  # noqa: BLE001 - a comparison figure, not the metric
+                    line["solves_host_core"] = {"error": repr(exc)}
                 try:
                     line["solves_scipy_core_pool"] = pool_solve_rate(ctx, mp, 32, solves["host_threads_per_gpu"])
                 except Exception as exc:  # noqa: BLE001 - a comparison figure, not the metric

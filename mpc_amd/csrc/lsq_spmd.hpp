@@ -25,6 +25,12 @@
 #define SPMD_HD
 #endif
 
+#if defined(__HIPCC__)
+#define SPMD_UNROLL _Pragma("unroll")
+#else
+#define SPMD_UNROLL
+#endif
+
 namespace lsqspmd {
 
 struct SerialTeam {
@@ -140,8 +146,21 @@ SPMD_HD int nnls(const Team &T, const Work &W, int mrow, int ncol, int mg, doubl
         PAR_FOR(T, t, iz1 - 1, iz2) {
             const int j = index[t];
             double s = 0.0;
-            for (int r = npp1; r <= m; ++r) {
-                const double br = b[r - 1];                 // a * (+-0.0) added to a sum that is never -0.0: no change
+            // a * (+-0.0) added to a sum that is never -0.0 changes nothing: rows where b is zero are not read.
+            // Eight rows at a time, loads first, so that a thread does not wait for each load in turn.
+            int r = npp1;
+            for (; r + 7 <= m; r += 8) {
+                double bv[8], av[8];
+                SPMD_UNROLL
+                for (int q = 0; q < 8; ++q) bv[q] = b[r - 1 + q];
+                SPMD_UNROLL
+                for (int q = 0; q < 8; ++q) av[q] = bv[q] != 0.0 ? AT(r + q, j) : 0.0;
+                SPMD_UNROLL
+                for (int q = 0; q < 8; ++q)
+                    if (bv[q] != 0.0) s = s + av[q] * bv[q];
+            }
+            for (; r <= m; ++r) {
+                const double br = b[r - 1];
                 if (br != 0.0) s = s + AT(r, j) * br;
             }
             w[j - 1] = s;
@@ -259,11 +278,27 @@ SPMD_HD int nnls(const Team &T, const Work &W, int mrow, int ncol, int mg, doubl
                 PAR_FOR(T, t, iz1 - 1, iz2) {
                     const int jj = index[t];
                     double sm = AT(nsetp, jj) * up;
-                    for (int r = npp1; r <= m; ++r) sm = sm + AT(r, jj) * W.piv[r - 1];
+                    int r = npp1;
+                    for (; r + 7 <= m; r += 8) {                // loads first, sums in order
+                        double av[8], pv8[8];
+                        SPMD_UNROLL
+                        for (int q = 0; q < 8; ++q) { av[q] = AT(r + q, jj); pv8[q] = W.piv[r - 1 + q]; }
+                        SPMD_UNROLL
+                        for (int q = 0; q < 8; ++q) sm = sm + av[q] * pv8[q];
+                    }
+                    for (; r <= m; ++r) sm = sm + AT(r, jj) * W.piv[r - 1];
                     if (sm != 0.0) {
                         sm = sm * bq;
                         AT(nsetp, jj) = AT(nsetp, jj) + sm * up;
-                        for (int r = npp1; r <= m; ++r) AT(r, jj) = AT(r, jj) + sm * W.piv[r - 1];
+                        r = npp1;
+                        for (; r + 7 <= m; r += 8) {
+                            double av[8], pv8[8];
+                            SPMD_UNROLL
+                            for (int q = 0; q < 8; ++q) { av[q] = AT(r + q, jj); pv8[q] = W.piv[r - 1 + q]; }
+                            SPMD_UNROLL
+                            for (int q = 0; q < 8; ++q) AT(r + q, jj) = av[q] + sm * pv8[q];
+                        }
+                        for (; r <= m; ++r) AT(r, jj) = AT(r, jj) + sm * W.piv[r - 1];
                     }
                 }
             }
@@ -389,11 +424,6 @@ SPMD_HD int nnls(const Team &T, const Work &W, int mrow, int ncol, int mg, doubl
 // of e, and every sum runs over k in ascending order as in the serial text.  Blocks of earlier columns in which none
 // of the R rows has a nonzero yet are left out of the sums: their entries are +-0.0, and +-0.0 * e added to a sum
 // that is +0.0 (or to any nonzero sum) changes nothing.
-#if defined(__HIPCC__)
-#define SPMD_UNROLL _Pragma("unroll")
-#else
-#define SPMD_UNROLL
-#endif
 #ifndef MPC_QP_NB
 #define MPC_QP_NB 2
 #endif

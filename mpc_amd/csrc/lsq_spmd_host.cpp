@@ -7,6 +7,11 @@
 #include "lsq_spmd.hpp"
 #include "slsqp_core.h"
 
+// diagnostic: NNLS iterations (columns entered or left) of the last mpc_lsq_spmd_serial call
+extern "C" {
+int mpc_lsq_spmd_nnls_iterations = 0;
+}
+
 extern "C" void mpc_lsq_spmd_serial(int m, int meq, int n, int nl, int la, double *l, double *g, double *a, double *b,
                                     double *xl, double *xu, double *x, double *y, double *w, int *jw, int *mode)
 {
@@ -29,6 +34,7 @@ extern "C" void mpc_lsq_spmd_serial(int m, int meq, int n, int nl, int la, doubl
     lsqspmd::Work W = lsqspmd::carve(dw.data(), dw.data() + lsqspmd::big_doubles(n, m), iw.data(), n, m, 1);
     for (int e = 0; e < nl; ++e) W.E[e] = l[e];                  // lsq works on its own copy of the factor
     *mode = lsqspmd::lsq(lsqspmd::SerialTeam(), W, H, g, b, nz.data(), xl, xu, x, yy.data());
+    mpc_lsq_spmd_nnls_iterations = W.isc[3];
     if (*mode == 1) {
         for (int i = 0; i < m; ++i) y[i] = yy[i];
         for (int i = m; i < m + 2 * n; ++i) y[i] = NAN;
