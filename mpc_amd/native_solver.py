@@ -417,31 +417,30 @@ class DeviceQpSLSQP:
     where the factor, the derivatives and the multipliers of every problem stay resident; the host threads
     keep the O(n + m) logic of the method (merit function, line search, convergence tests).  Per QP only the box,
     the last step and the new step with its multipliers cross PCIe, staged into one copy each way per round.
-    ``lanes`` = 2 splits a batch into two halves, each with its own stream, context and host threads: while one
-    half's kernels run, the other half's host logic and copies proceed.  Results equal the host drivers' bit for
+    ``lanes`` > 1 splits a batch into that many parts, each with its own stream, context and host threads: while one
+    part's kernels run, the others' host logic and copies proceed.  Results equal the host drivers' bit for
     bit.  A problem whose linearisation turns out inconsistent (Kraft's augmented problem) is solved again by the
     host-only driver."""
 
     MIN_PER_LANE = 64          # below this a second lane only adds launches
 
-    def __init__(self, ctx: MpcContext, threads: int = 0, capacity: int = None, lanes: int = 2):
+    def __init__(self, ctx: MpcContext, threads: int = 0, capacity: int = None, lanes: int = 4):
         if not ctx.nz_supported():
             raise ValueError("the driver takes dc/dx in its structured form: the context needs MPC_ALGO_PREFIX")
-        if lanes not in (1, 2):
-            raise ValueError("lanes must be 1 or 2")
+        if not 1 <= lanes <= 4:
+            raise ValueError("lanes must be 1..4")
         self.ctx = ctx
         self.cap = cap = int(capacity or ctx.max_scenarios)
         self.threads = threads
-        if cap < 2 * self.MIN_PER_LANE:
-            lanes = 1
+        lanes = max(1, min(lanes, cap // self.MIN_PER_LANE))
         lane_cap = (cap + lanes - 1) // lanes
-        lane_threads = threads if lanes == 1 or threads <= 0 else max(1, (threads + 1) // 2)
+        lane_threads = threads if lanes == 1 or threads <= 0 else max(1, (threads + lanes - 1) // lanes)
         self._ctxs = [ctx] + [MpcContext(ctx.params, lane_cap, ctx.device_index) for _ in range(lanes - 1)]
         self.lanes = [_DeviceQpLane(c, lane_threads, lane_cap) for c in self._ctxs]
-        if lanes == 2:
+        if lanes > 1:
             from concurrent.futures import ThreadPoolExecutor
 
-            self._helper = ThreadPoolExecutor(max_workers=1)
+            self._helper = ThreadPoolExecutor(max_workers=lanes - 1)
         self._host_fallback = None
 
     def solve(self, sc: ScenarioBatch, x0: np.ndarray) -> BatchSolveResult:
@@ -458,15 +457,17 @@ class DeviceQpSLSQP:
         for lane in self.lanes:
             lane.stream.wait_stream(caller)              # the scenarios were written on the caller's stream
         if len(self.lanes) == 1 or (N < 2 * self.MIN_PER_LANE and N <= self.lanes[0].cap):
-            parts, cuts = [self.lanes[0].solve(sc, x0)], [0, N]
+            parts = [self.lanes[0].solve(sc, x0)]
         else:
-            half = (N + 1) // 2
-            other = self._helper.submit(self.lanes[1].solve, sc.slice(half, N), x0[half:])
+            k = len(self.lanes)
+            cuts = [(N * i) // k for i in range(k + 1)]
+            others = [self._helper.submit(self.lanes[i].solve, sc.slice(cuts[i], cuts[i + 1]), x0[cuts[i]:cuts[i + 1]])
+                      for i in range(1, k)]
             try:
-                first = self.lanes[0].solve(sc.slice(0, half), x0[:half])
+                first = self.lanes[0].solve(sc.slice(0, cuts[1]), x0[:cuts[1]])
             finally:
-                second = other.result()
-            parts, cuts = [first, second], [0, half, N]
+                rest = [o.result() for o in others]
+            parts = [first] + rest
         x = np.concatenate([r.x for r in parts])
         fun = np.concatenate([r.fun for r in parts])
         nit = np.concatenate([r.nit for r in parts])

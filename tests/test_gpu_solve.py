@@ -431,7 +431,7 @@ def test_device_qp_driver_equals_host_driver():
     from mpc_amd.native_solver import DeviceQpSLSQP, NativeBatchedSLSQP
     from mpc_amd.scenarios import to_device
 
-    # capacity 256: two lanes of 128; the batches of 150 and 200 run as two halves on two streams, the small ones on one
+    # capacity 256: four lanes of 64; the batches of 150 and 200 run as four parts on four streams, the small ones on one
     for H, count, prev in ((1, 9, False), (3, 200, True), (20, 24, False), (20, 150, False)):
         mp = MpcParams.reference_yaml_defaults(horizon=H)
         ctx = MpcContext(mp, 256, 0)
@@ -440,7 +440,7 @@ def test_device_qp_driver_equals_host_driver():
         with NativeBatchedSLSQP(ctx, threads=3) as host:
             one = host.solve(sc, hs.x)
         with DeviceQpSLSQP(ctx, threads=3) as dev:
-            assert len(dev.lanes) == 2
+            assert len(dev.lanes) == 4
             two = dev.solve(sc, hs.x)
             again = dev.solve(sc.slice(0, 5), hs.x[:5])
         np.testing.assert_array_equal(two.status, one.status)
