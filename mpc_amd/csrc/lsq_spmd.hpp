@@ -315,8 +315,17 @@ SPMD_HD int nnls(const Team &T, const Work &W, int mrow, int ncol, int mg, doubl
                 for (int ip = nsetp; ip >= 1; --ip) {
                     if (ip != nsetp) {
                         const double zf = -z[ip];
-                        if (zf != 0.0)
-                            for (int r = 1; r <= ip; ++r) z[r - 1] = z[r - 1] + zf * AT(r, jj);
+                        if (zf != 0.0) {
+                            int r = 1;
+                            for (; r + 7 <= ip; r += 8) {              // independent entries: loads first
+                                double av[8];
+                                SPMD_UNROLL
+                                for (int q = 0; q < 8; ++q) av[q] = AT(r + q, jj);
+                                SPMD_UNROLL
+                                for (int q = 0; q < 8; ++q) z[r - 1 + q] = z[r - 1 + q] + zf * av[q];
+                            }
+                            for (; r <= ip; ++r) z[r - 1] = z[r - 1] + zf * AT(r, jj);
+                        }
                     }
                     jj = index[ip - 1];
                     z[ip - 1] = z[ip - 1] / AT(ip, jj);
@@ -735,13 +744,13 @@ SPMD_HD void ldl(const Team &T, const Work &W, int n, double *a, double *z, doub
         T.sync();
         for (int i = 1; i <= n; ++i) {
             const double v = w[i - 1];
-            t = t + v * v / a[ij - 1];
+            if (T.tid() == 0) t = t + v * v / a[ij - 1];          // only thread 0 carries t through this loop
             PAR_FOR(T, j, i + 1, n + 1) w[j - 1] = w[j - 1] - v * a[ij - 1 + (j - i)];
             T.sync();
             ij = ij + (n - i) + 1;
         }
-        if (t >= 0.0) t = 2.22e-16 / sigma;
         if (T.tid() == 0) {
+            if (t >= 0.0) t = 2.22e-16 / sigma;
             int q = ij;
             double tt = t;
             for (int i = 1; i <= n; ++i) {
@@ -758,34 +767,39 @@ SPMD_HD void ldl(const Team &T, const Work &W, int n, double *a, double *z, doub
         ij = ij - (n * (n + 1)) / 2;
         T.sync();
     }
+    const bool owner = T.tid() < n;            // the threads that ever own a row: the others only keep the barriers
     for (int i = 1; i <= n; ++i) {
-        const double v = z[i - 1], aij = a[ij - 1];
-        const double delta = v / aij;
-        double tp = 0.0;
-        if (sigma < 0.0) tp = w[i - 1];
-        if (sigma > 0.0) tp = t + delta * v;
-        const double alpha = tp / t;
-        if (T.tid() == 0) dnew[i - 1] = alpha * aij;
-        if (i == n) break;
-        const double beta = delta / tp;
-        if (alpha > 4.0) {
-            const double gamma = t / tp;
-            PAR_FOR(T, j, i + 1, n + 1) {
-                const int p = ij - 1 + (j - i);
-                const double u = a[p];
-                a[p] = gamma * u + beta * z[j - 1];
-                z[j - 1] = z[j - 1] - v * u;
+        if (owner) {
+            const double v = z[i - 1], aij = a[ij - 1];
+            const double delta = v / aij;
+            double tp = 0.0;
+            if (sigma < 0.0) tp = w[i - 1];
+            if (sigma > 0.0) tp = t + delta * v;
+            const double alpha = tp / t;
+            if (T.tid() == 0) dnew[i - 1] = alpha * aij;
+            if (i < n) {
+                const double beta = delta / tp;
+                if (alpha > 4.0) {
+                    const double gamma = t / tp;
+                    PAR_FOR(T, j, i + 1, n + 1) {
+                        const int p = ij - 1 + (j - i);
+                        const double u = a[p];
+                        a[p] = gamma * u + beta * z[j - 1];
+                        z[j - 1] = z[j - 1] - v * u;
+                    }
+                } else {
+                    PAR_FOR(T, j, i + 1, n + 1) {
+                        const int p = ij - 1 + (j - i);
+                        z[j - 1] = z[j - 1] - v * a[p];
+                        a[p] = a[p] + beta * z[j - 1];
+                    }
+                }
             }
-        } else {
-            PAR_FOR(T, j, i + 1, n + 1) {
-                const int p = ij - 1 + (j - i);
-                z[j - 1] = z[j - 1] - v * a[p];
-                a[p] = a[p] + beta * z[j - 1];
-            }
+            t = tp;
         }
+        if (i == n) break;
         T.sync();
         ij = ij + (n - i) + 1;
-        t = tp;
     }
     T.sync();
     PAR_FOR(T, i, 0, n) a[i * n - (i * (i - 1)) / 2] = dnew[i];
