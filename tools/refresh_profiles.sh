@@ -21,3 +21,11 @@ bash tools/pmc.sh $out/pmc 20 65536 0 > $out/pmc_summary.txt
 echo "pmc (dense dc/dx) done"
 bash tools/pmc.sh $out/pmc_nojac 20 65536 0 nojac > $out/pmc_summary_nojac.txt
 echo "pmc (gradient only) done"
+cd /tmp
+timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt_qp -- python3 $R/tools/qp_time.py 4096 > $out/qp_time.txt 2> $out/kt_qp.log
+echo "kernel trace QP done"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt_solve -- python3 $R/tools/solve_full.py 65536 15 $out/solve_cfg3_65536_device_qp.json device_qp > $out/solve_full.txt 2> $out/kt_solve.log
+echo "kernel trace full-size solve done"
+cd $R
+bash tools/pmc_qp.sh $out/pmc_qp 4096 > $out/pmc_summary_qp.txt
+echo "pmc (QP kernel) done"

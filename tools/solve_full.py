@@ -1,5 +1,5 @@
 """BASELINE.json configs[2] at full size: N angular-motion scenarios, H=20, one full SLSQP solve each,
-through the solver pool.  usage: solve_full.py [N] [workers] [out.json] [native|pool]"""
+through the solver pool.  usage: solve_full.py [N] [workers] [out.json] [device_qp|native|pool]"""
 import os, sys; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import json
 import time
@@ -24,10 +24,11 @@ def main():
     t_gen = time.perf_counter() - t0
     print(f"{N} scenarios generated in {t_gen:.1f} s; {W} workers", flush=True)
     driver = sys.argv[4] if len(sys.argv) > 4 else "native"
-    if driver == "native":
-        from mpc_amd.native_solver import NativeBatchedSLSQP
+    if driver in ("native", "device_qp"):
+        from mpc_amd.native_solver import DeviceQpSLSQP, NativeBatchedSLSQP
 
-        with NativeBatchedSLSQP(ctx, threads=W, capacity=N) as native:
+        with (NativeBatchedSLSQP if driver == "native" else DeviceQpSLSQP)(ctx, threads=W, capacity=N) as native:
+            BatchedMPC(ctx, solver=native).compute_control(hs.q0[:64], hs.state0[:64, 12:18], hs.target[:64], hs.base[:64])  # warm
             bm = BatchedMPC(ctx, solver=native)
             t0 = time.perf_counter()
             u = bm.compute_control(hs.q0, hs.state0[:, 12:18], hs.target, hs.base)
@@ -48,6 +49,9 @@ def main():
            "mean_iterations": float(r.nit.mean()), "max_iterations": int(r.nit.max()), "n_eval": r.n_eval, "n_eval_fd": r.n_eval_fd,
            "max_core_seconds_per_worker": r.t_core, "server_busy_seconds": r.t_serve, "scenario_generation_seconds": t_gen,
            "max_abs_control": float(np.abs(u).max()), "all_finite": bool(np.isfinite(u).all())}
+    if driver == "device_qp":
+        res["qp_subproblems_on_gpu"] = int(r.n_qp)
+        res["solved_again_on_host"] = int(r.n_host_fallback)
     print(json.dumps(res), flush=True)
     if out:
         with open(out, "w") as f:
