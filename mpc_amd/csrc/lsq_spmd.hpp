@@ -117,10 +117,16 @@ SPMD_HD inline double nrm2(int n, const double *dx, int incx)
 SPMD_HD inline double sum_in_order(double t, const double *p, int count)
 {
     int j = 0;
-    for (; j + 8 <= count; j += 8) {
-        const double p0 = p[j], p1 = p[j + 1], p2 = p[j + 2], p3 = p[j + 3], p4 = p[j + 4], p5 = p[j + 5], p6 = p[j + 6],
-                     p7 = p[j + 7];
-        t = t + p0; t = t + p1; t = t + p2; t = t + p3; t = t + p4; t = t + p5; t = t + p6; t = t + p7;
+    for (; j + 16 <= count; j += 16) {
+        double v[16];
+        SPMD_UNROLL
+        for (int q = 0; q < 16; ++q) v[q] = p[j + q];
+        SPMD_UNROLL
+        for (int q = 0; q < 16; ++q) t = t + v[q];
+    }
+    for (; j + 4 <= count; j += 4) {
+        const double p0 = p[j], p1 = p[j + 1], p2 = p[j + 2], p3 = p[j + 3];
+        t = t + p0; t = t + p1; t = t + p2; t = t + p3;
     }
     for (; j < count; ++j) t = t + p[j];
     return t;
@@ -682,9 +688,18 @@ SPMD_HD int lsq(const Team &T, const Work &W, int H, const double *g, const doub
     PAR_FOR(T, j, 0, n + 1) {
         const double *gj = W.G + (size_t)j * mg;
         double t = 0.0;
-        for (int i = 0; i < mg; ++i) {
+        int i = 0;
+        for (; i + 8 <= mg; i += 8) {                      // rows outside the set: not stored, not read
+            double xv[8];
+            SPMD_UNROLL
+            for (int q = 0; q < 8; ++q) xv[q] = W.xn[i + q];
+            SPMD_UNROLL
+            for (int q = 0; q < 8; ++q)
+                if (xv[q] != 0.0) t = t + gj[i + q] * xv[q];
+        }
+        for (; i < mg; ++i) {
             const double xi = W.xn[i];
-            if (xi != 0.0) t = t + gj[i] * xi;             // rows outside the set: not stored, not read
+            if (xi != 0.0) t = t + gj[i] * xi;
         }
         W.zz[j] = t;
     }
@@ -706,13 +721,23 @@ SPMD_HD int lsq(const Team &T, const Work &W, int H, const double *g, const doub
     //      chain (thread 0); the products are formed by the team first.
     PAR_FOR(T, i, 0, n) W.xs[i] = W.xs[i] + 1.0 * W.ff[i];
     T.sync();
+    // Row i needs the products e(i, j) x(j), j > i, added in ascending j.  All but the first are ready one row
+    // earlier, so while thread 0 adds up row i the team already forms row i - 1's products for j > i (two
+    // buffers, used alternately); thread 0 only adds the product with the x(i + 1) it has just finished.
     for (int i = n - 1; i >= 0; --i) {
         const double *er = W.E + EO(i) - i;                // er[j] = e(i, j)
-        PAR_FOR(T, j, i + 1, n) W.piv[j] = er[j] * W.xs[j];
-        T.sync();
+        double *mine = (i & 1) ? W.piv : W.zz, *next = (i & 1) ? W.zz : W.piv;
         if (T.tid() == 0) {
-            const double t = sum_in_order(0.0, W.piv + i + 1, n - i - 1);
+            double t = 0.0;
+            if (i + 1 < n) {
+                t = t + er[i + 1] * W.xs[i + 1];
+                t = sum_in_order(t, mine + i + 2, n - i - 2);
+            }
             W.xs[i] = (W.xs[i] - t) / er[i];
+        }
+        if (i > 0) {
+            const double *eu = W.E + EO(i - 1) - (i - 1);  // eu[j] = e(i - 1, j)
+            PAR_FOR(T, j, i + 1, n) next[j] = eu[j] * W.xs[j];
         }
         T.sync();
     }
@@ -740,25 +765,30 @@ SPMD_HD void ldl(const Team &T, const Work &W, int n, double *a, double *z, doub
     double t = 1.0 / sigma;
     int ij = 1;
     if (sigma <= 0.0) {
+        // w <- L^-1 z column by column; t + sum of w(i)^2 / d(i) forwards, then the same terms taken off again
+        // backwards with the running value left in w.  The quotients do not depend on the running value: the team
+        // forms them (W.acc[2n..3n)), thread 0 keeps the two chains of additions, in the serial order.
+        double *quot = W.acc + 2 * n;
         PAR_FOR(T, i, 0, n) w[i] = z[i];
         T.sync();
         for (int i = 1; i <= n; ++i) {
             const double v = w[i - 1];
-            if (T.tid() == 0) t = t + v * v / a[ij - 1];          // only thread 0 carries t through this loop
             PAR_FOR(T, j, i + 1, n + 1) w[j - 1] = w[j - 1] - v * a[ij - 1 + (j - i)];
             T.sync();
             ij = ij + (n - i) + 1;
         }
+        PAR_FOR(T, i, 0, n) {
+            const double v = w[i];
+            quot[i] = v * v / a[i * n - (i * (i - 1)) / 2];
+        }
+        T.sync();
         if (T.tid() == 0) {
+            t = sum_in_order(t, quot, n);
             if (t >= 0.0) t = 2.22e-16 / sigma;
-            int q = ij;
             double tt = t;
-            for (int i = 1; i <= n; ++i) {
-                const int j = n + 1 - i;
-                q = q - i;
-                const double u = w[j - 1];
+            for (int j = n; j >= 1; --j) {
                 w[j - 1] = tt;
-                tt = tt - u * u / a[q - 1];
+                tt = tt - quot[j - 1];
             }
             W.sc[4] = tt;
         }
