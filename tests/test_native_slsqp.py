@@ -149,3 +149,48 @@ def test_team_parallel_lsq_with_a_team_of_one_keeps_whole_solves_identical(H, N)
         np.testing.assert_array_equal(xa, xb)
     np.testing.assert_array_equal(got[1], want[1])
     np.testing.assert_array_equal(got[2], want[2])
+
+
+def test_offload_staging_packs_and_unpacks_rows():
+    """mpc_slsqp_pack / mpc_slsqp_unpack (QP offload): one round's requests gathered into / scattered from flat
+    staging buffers with the layouts include/mpc_slsqp.h gives."""
+    import ctypes as C
+
+    H, N = 3, 7
+    n, m = 6 * H, 12 * (H + 1)
+    rng = np.random.default_rng(3)
+    lb, ub = -0.5 * np.ones(n), 0.5 * np.ones(n)
+    b = NativeBatch(H, N, threads=2, offload_qp=True)
+    b.begin(rng.uniform(-0.4, 0.4, (N, n)), lb, ub, 1e-3, 50)
+    b.X[:N] += rng.uniform(-0.3, 0.3, (N, n))             # some entries outside the box: pack must clip them
+    b.LO[:N, :n], b.HI[:N, :n], b.S[:N, :n] = rng.normal(size=(3, N, n))
+    flags = np.ctypeslib.as_array(b._lib.mpc_slsqp_qp_flags(b._b), shape=(N,))
+    wf, wg, wq = np.array([5, 0], np.int32), np.array([2], np.int32), np.array([6, 1, 3], np.int32)
+    nf, ng, nq = len(wf), len(wg), len(wq)
+    stage, istage = np.full((nf + ng + 3 * nq) * n, np.nan), np.full(nf + ng + 2 * nq, -7, np.int32)
+    i32 = lambda a: a.ctypes.data_as(C.POINTER(C.c_int32))
+    assert b._lib.mpc_slsqp_pack(b._b, nf, i32(wf), ng, i32(wg), nq, i32(wq), stage.ctypes.data, istage.ctypes.data) == 0
+    want = np.concatenate([np.clip(b.X[wf], lb, ub).ravel(), np.clip(b.X[wg], lb, ub).ravel(), b.LO[wq, :n].ravel(),
+                           b.HI[wq, :n].ravel(), b.S[wq, :n].ravel()])
+    np.testing.assert_array_equal(stage, want)
+    np.testing.assert_array_equal(istage, np.concatenate([wf, wg, wq, flags[wq]]))
+    # the way back: c, grad f, step, multipliers, f; a step is taken only where the QP's mode is 1
+    back = rng.normal(size=nf * m + ng * n + nq * (n + m) + nf)
+    modes = np.array([1, 4, 1], np.int32)
+    s_before, r_before = b.S[:N].copy(), b.R[:N].copy()
+    assert b._lib.mpc_slsqp_unpack(b._b, nf, i32(wf), ng, i32(wg), nq, i32(wq), back.ctypes.data, modes.ctypes.data) == 0
+    c, g, s, r, f = np.split(back, np.cumsum([nf * m, ng * n, nq * n, nq * m]))
+    np.testing.assert_array_equal(b.Cc[wf], c.reshape(nf, m))
+    np.testing.assert_array_equal(b.F[wf], f)
+    np.testing.assert_array_equal(b.G[wg, :n], g.reshape(ng, n))
+    np.testing.assert_array_equal(b.QPMODE[wq], modes)
+    ok = modes == 1
+    np.testing.assert_array_equal(b.S[wq[ok], :n], s.reshape(nq, n)[ok])
+    np.testing.assert_array_equal(b.R[wq[ok], :m], r.reshape(nq, m)[ok])
+    np.testing.assert_array_equal(b.S[wq[~ok]], s_before[wq[~ok]])
+    np.testing.assert_array_equal(b.R[wq[~ok]], r_before[wq[~ok]])
+    assert b._lib.mpc_slsqp_pack(b._b, -1, i32(wf), 0, i32(wg), 0, i32(wq), stage.ctypes.data, istage.ctypes.data) == -1
+    b.close()
+    plain = NativeBatch(H, N, threads=1)                   # not in offload mode: refused
+    assert plain._lib.mpc_slsqp_pack(plain._b, 0, i32(wf), 0, i32(wg), 0, i32(wq), stage.ctypes.data, istage.ctypes.data) == -1
+    plain.close()
