@@ -432,7 +432,8 @@ def test_device_qp_driver_equals_host_driver():
     from mpc_amd.scenarios import to_device
 
     # capacity 256: four lanes of 64; the batches of 150 and 200 run as four parts on four streams, the small ones on one
-    for H, count, prev in ((1, 9, False), (3, 200, True), (20, 24, False), (20, 150, False)):
+    # H = 32: the team's triangle and vectors (175 KB) no longer fit LDS and live in its global workspace slice
+    for H, count, prev in ((1, 9, False), (3, 200, True), (20, 24, False), (20, 150, False), (32, 6, False)):
         mp = MpcParams.reference_yaml_defaults(horizon=H)
         ctx = MpcContext(mp, 256, 0)
         _, hs = host_scenarios(mp, count, motion="angular", cfg_id=19, with_prev=prev)
