@@ -442,6 +442,9 @@ SPMD_HD int nnls(const Team &T, const Work &W, int mrow, int ncol, int mg, doubl
 #ifndef MPC_QP_NB
 #define MPC_QP_NB 2
 #endif
+#ifndef MPC_QP_ROWS
+#define MPC_QP_ROWS 2
+#endif
 
 struct RowDesc {
     int a, first, last, kind, kk;      // sub-blocks [first, last] hold the row's nonzeros, in column 6 * jj + a of each
@@ -660,11 +663,17 @@ SPMD_HD int lsq(const Team &T, const Work &W, int H, const double *g, const doub
     T.sync();
     if (!W.isc[8]) return 5;
     // ---- [g h] <- [g e^-1, h - g f], one row per index, into the matrix NNLS works on
-    //      (two rows per index, half the matrix apart: they share the reads of e)
-    PAR_FOR(T, i, 0, mg / 2) {
-        const int rows[2] = {i, i + mg / 2};
-        double *const dst[2] = {W.AT + i, W.AT + i + mg / 2};
-        transform_rows<2>(W, H, rows, cvals, nz, lo, hi, dst);
+    //      (MPC_QP_ROWS rows per index, spread evenly over the matrix: they share the reads of e; m + 2n = 12(2H + 1)
+    //      is a multiple of 2, 3 and 4)
+    PAR_FOR(T, i, 0, mg / MPC_QP_ROWS) {
+        int rows[MPC_QP_ROWS];
+        double *dst[MPC_QP_ROWS];
+        SPMD_UNROLL
+        for (int r = 0; r < MPC_QP_ROWS; ++r) {
+            rows[r] = i + r * (mg / MPC_QP_ROWS);
+            dst[r] = W.AT + rows[r];
+        }
+        transform_rows<MPC_QP_ROWS>(W, H, rows, cvals, nz, lo, hi, dst);
     }
     // ---- LDP: NNLS on the copy of [g h]^T with right-hand side e_{n+1}
     PAR_FOR(T, i, 0, n) W.bb[i] = 0.0;
