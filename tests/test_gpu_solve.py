@@ -431,7 +431,8 @@ def test_device_qp_driver_equals_host_driver():
     from mpc_amd.native_solver import DeviceQpSLSQP, NativeBatchedSLSQP
     from mpc_amd.scenarios import to_device
 
-    # capacity 256: four lanes of 64; the batches of 150 and 200 run as four parts on four streams, the small ones on one
+    # capacity 256, at least 32 per lane: four lanes of 64; the batches of 150 and 200 run as four parts on four streams,
+    # the small ones on one
     # H = 32: the team's triangle and vectors (175 KB) no longer fit LDS and live in its global workspace slice
     for H, count, prev in ((1, 9, False), (3, 200, True), (20, 24, False), (20, 150, False), (32, 6, False)):
         mp = MpcParams.reference_yaml_defaults(horizon=H)
@@ -440,7 +441,7 @@ def test_device_qp_driver_equals_host_driver():
         sc, _ = to_device(ctx, hs)
         with NativeBatchedSLSQP(ctx, threads=3) as host:
             one = host.solve(sc, hs.x)
-        with DeviceQpSLSQP(ctx, threads=3) as dev:
+        with DeviceQpSLSQP(ctx, threads=3, min_per_lane=32) as dev:
             assert len(dev.lanes) == 4
             two = dev.solve(sc, hs.x)
             again = dev.solve(sc.slice(0, 5), hs.x[:5])
