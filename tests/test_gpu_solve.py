@@ -319,6 +319,27 @@ def test_closed_loop_through_the_pool_equals_one_process():
     np.testing.assert_array_equal(many.converged, one.converged)
 
 
+def test_closed_loop_with_the_qp_on_the_device_equals_one_process():
+    """Six ticks of 24 controllers at H=20 and of 160 at H=3 (two lanes): with the BFGS update and the QP of every
+    iteration on the GPU the trajectories are those of scipy's own core, bit for bit (warm starts, EMA, clip
+    included)."""
+    from helpers import host_scenarios
+    from mpc_amd.batch import MpcContext
+    from mpc_amd.closed_loop import run_closed_loop
+    from mpc_amd.native_solver import DeviceQpSLSQP
+
+    for H, N, ticks in ((20, 24, 4), (3, 160, 6)):
+        mp = MpcParams.reference_yaml_defaults(horizon=H)
+        ctx = MpcContext(mp, N, 0)
+        _, hs = host_scenarios(mp, N, motion="angular", cfg_id=16)
+        one = run_closed_loop(ctx, hs.q0, "angular", hs.amplitude, hs.phase, ticks=ticks)
+        with DeviceQpSLSQP(ctx, threads=3, capacity=N, lanes=2, min_per_lane=64) as dev:
+            many = run_closed_loop(ctx, hs.q0, "angular", hs.amplitude, hs.phase, ticks=ticks, solver=dev)
+        np.testing.assert_array_equal(many.q, one.q)
+        np.testing.assert_array_equal(many.u, one.u)
+        np.testing.assert_array_equal(many.converged, one.converged)
+
+
 def test_native_driver_equals_scipy_core_driver():
     """libmpc_slsqp.so (C core on host threads, evaluations from the GPU) against the lock-step driver over
     scipy's compiled core: identical iterates, exit modes, iteration counts and evaluation counts."""
