@@ -177,7 +177,10 @@ int mpc_prepare_tick(mpc_ctx *ctx, int count, const double *q, const double *dq,
  * Outputs: s [count][n] the step, y [count][m + 2n] the multipliers (constraint rows first), mode [count]
  * (1 = solved, otherwise the code the SLSQP body hands on, 4 = inconsistent linearisation).  The arithmetic
  * is the host core's (mpc_amd/csrc/slsqp_core.c), entry for entry, so results are bit-identical to it and to
- * scipy's.  All pointers are device pointers.  Needs a context whose horizon matches. */
+ * scipy's.  All pointers are device pointers.  Needs a context whose horizon matches.  The first call on a context
+ * allocates the workspace of its resident workgroups (two per CU while the packed triangle and the vectors fit
+ * LDS, H <= 26: 0.95 MB each at H = 20, 0.5 GB per context on MI355X); like every call on one context, QP calls
+ * must not overlap each other (one workspace): concurrent callers use one context each. */
 int mpc_qp_solve(mpc_ctx *ctx, int count, const double *l, const double *g, const double *c, const double *nz,
                  const double *lo, const double *hi, double *s, double *y, int32_t *mode, void *stream);
 
