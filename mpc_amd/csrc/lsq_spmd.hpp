@@ -762,87 +762,98 @@ SPMD_HD int lsq(const Team &T, const Work &W, int H, const double *g, const doub
 }
 
 // Rank-one update of the LDL' factorisation a (packed by columns) with z and sigma; w is work (Fletcher &
-// Powell's composite-t method as in slsqp_core.c's ldl).  The outer recurrence runs in step on every thread
-// (each recomputes the scalars from values that are final after the previous barrier); the inner loops
-// over the rows below the diagonal are the parallel part.  New diagonals are parked in W.acc[n..2n) and
-// written back at the end, so that no thread reads a diagonal another one is replacing.
+// Powell's composite-t method as in slsqp_core.c's ldl).  The serial text interleaves three things per column i:
+// the pivot v(i) = z(i) after the earlier columns' eliminations, the scalars (t, alpha, beta, gamma) and the update of
+// the column's entries.  They separate without changing one rounded value:
+//   A  v = L^-1 z by forward substitution, column-oriented (the eliminations only ever read OLD entries of a);
+//      for sigma < 0 the same sweep is the serial text's preliminary pass;
+//   B  the scalars: quotients and products per index, the running sums t as one chain of additions on thread 0;
+//   C  the entries, one ROW per index: row j walks its columns i < j in order, carrying its own z(j) through the same
+//      eliminations again, with no barrier in between.
+// Scratch: W.acc[0..3n) and W.xn[0..4n) (both free outside the QP).
 template <class Team>
 SPMD_HD void ldl(const Team &T, const Work &W, int n, double *a, double *z, double sigma, double *w)
 {
     if (sigma == 0.0) return;
-    double *dnew = W.acc + n;
-    double t = 1.0 / sigma;
-    int ij = 1;
-    if (sigma <= 0.0) {
-        // w <- L^-1 z column by column; t + sum of w(i)^2 / d(i) forwards, then the same terms taken off again
-        // backwards with the running value left in w.  The quotients do not depend on the running value: the team
-        // forms them (W.acc[2n..3n)), thread 0 keeps the two chains of additions, in the serial order.
-        double *quot = W.acc + 2 * n;
-        PAR_FOR(T, i, 0, n) w[i] = z[i];
-        T.sync();
-        for (int i = 1; i <= n; ++i) {
-            const double v = w[i - 1];
-            PAR_FOR(T, j, i + 1, n + 1) w[j - 1] = w[j - 1] - v * a[ij - 1 + (j - i)];
+    double *vv = W.acc, *dnew = W.acc + n, *quot = W.acc + 2 * n;
+    double *alp = W.xn, *bet = W.xn + n, *gam = W.xn + 2 * n, *tpv = W.xn + 3 * n;
+#define DIAG(i) ((i) * n - ((i) * ((i) - 1)) / 2)
+    // ---- A
+    PAR_FOR(T, i, 0, n) vv[i] = z[i];
+    T.sync();
+    {
+        int ij = 1;
+        for (int i = 1; i < n; ++i) {
+            const double v = vv[i - 1];
+            PAR_FOR(T, j, i + 1, n + 1) vv[j - 1] = vv[j - 1] - v * a[ij - 1 + (j - i)];
             T.sync();
             ij = ij + (n - i) + 1;
         }
+    }
+    // ---- B
+    double t0 = 1.0 / sigma;
+    if (sigma <= 0.0) {
+        PAR_FOR(T, i, 0, n) quot[i] = vv[i] * vv[i] / a[DIAG(i)];
+        T.sync();
+        if (T.tid() == 0) {
+            double t = sum_in_order(t0, quot, n);
+            if (t >= 0.0) t = 2.22e-16 / sigma;
+            for (int j = n; j >= 1; --j) {
+                w[j - 1] = t;
+                t = t - quot[j - 1];
+            }
+            W.sc[4] = t;
+        }
+        T.sync();
+        t0 = W.sc[4];
+        PAR_FOR(T, i, 0, n) tpv[i] = w[i];
+    } else {
         PAR_FOR(T, i, 0, n) {
-            const double v = w[i];
-            quot[i] = v * v / a[i * n - (i * (i - 1)) / 2];
+            const double delta = vv[i] / a[DIAG(i)];
+            quot[i] = delta * vv[i];
         }
         T.sync();
         if (T.tid() == 0) {
-            t = sum_in_order(t, quot, n);
-            if (t >= 0.0) t = 2.22e-16 / sigma;
-            double tt = t;
-            for (int j = n; j >= 1; --j) {
-                w[j - 1] = tt;
-                tt = tt - quot[j - 1];
+            double t = t0;
+            for (int i = 0; i < n; ++i) {
+                t = t + quot[i];
+                tpv[i] = t;
             }
-            W.sc[4] = tt;
         }
-        T.sync();
-        t = W.sc[4];
-        ij = ij - (n * (n + 1)) / 2;
-        T.sync();
-    }
-    const bool owner = T.tid() < n;            // the threads that ever own a row: the others only keep the barriers
-    for (int i = 1; i <= n; ++i) {
-        if (owner) {
-            const double v = z[i - 1], aij = a[ij - 1];
-            const double delta = v / aij;
-            double tp = 0.0;
-            if (sigma < 0.0) tp = w[i - 1];
-            if (sigma > 0.0) tp = t + delta * v;
-            const double alpha = tp / t;
-            if (T.tid() == 0) dnew[i - 1] = alpha * aij;
-            if (i < n) {
-                const double beta = delta / tp;
-                if (alpha > 4.0) {
-                    const double gamma = t / tp;
-                    PAR_FOR(T, j, i + 1, n + 1) {
-                        const int p = ij - 1 + (j - i);
-                        const double u = a[p];
-                        a[p] = gamma * u + beta * z[j - 1];
-                        z[j - 1] = z[j - 1] - v * u;
-                    }
-                } else {
-                    PAR_FOR(T, j, i + 1, n + 1) {
-                        const int p = ij - 1 + (j - i);
-                        z[j - 1] = z[j - 1] - v * a[p];
-                        a[p] = a[p] + beta * z[j - 1];
-                    }
-                }
-            }
-            t = tp;
-        }
-        if (i == n) break;
-        T.sync();
-        ij = ij + (n - i) + 1;
     }
     T.sync();
-    PAR_FOR(T, i, 0, n) a[i * n - (i * (i - 1)) / 2] = dnew[i];
+    PAR_FOR(T, i, 0, n) {
+        const double aii = a[DIAG(i)], tp = tpv[i], t = i == 0 ? t0 : tpv[i - 1];
+        const double delta = vv[i] / aii;
+        const double alpha = tp / t;
+        dnew[i] = alpha * aii;
+        alp[i] = alpha;
+        bet[i] = delta / tp;
+        gam[i] = t / tp;
+    }
     T.sync();
+    // ---- C
+    PAR_FOR(T, j, 1, n) {
+        double zj = z[j];
+        for (int i = 0; i < j; ++i) {
+            const int p = DIAG(i) + (j - i);
+            const double v = vv[i], u = a[p];
+            if (alp[i] > 4.0) {
+                a[p] = gam[i] * u + bet[i] * zj;
+                zj = zj - v * u;
+            } else {
+                zj = zj - v * u;
+                a[p] = u + bet[i] * zj;
+            }
+        }
+    }
+    T.sync();
+    PAR_FOR(T, i, 0, n) {
+        a[DIAG(i)] = dnew[i];
+        z[i] = vv[i];
+    }
+    T.sync();
+#undef DIAG
 }
 
 // The modified BFGS update of SLSQP's major iteration (the block after the derivatives arrive, before the
