@@ -102,14 +102,7 @@ qp_step_kernel(int H, int count, const int32_t *__restrict__ index, const int32_
         T.sync();
         if (md == 1) {
             PAR_FOR(T, i, 0, n) {
-                const int j = i / 6, a = i % 6;
-                const int tri = j * H - (j * (j - 1)) / 2 - j - 1;
-                double t = 0.0;                                  // column i of dc/dx times r, rows ascending
-                for (int kk = j + 1; kk <= H; ++kk) {
-                    t = t + nz[6 * H + 6 * (tri + kk) + a] * r[12 * kk + a];
-                    if (kk == j + 1) t = t + nz[i] * r[12 * (j + 1) + 6 + a];
-                }
-                v[i] = g[i] - t;
+                v[i] = g[i] - lsqspmd::jac_column_dot(H, nz, r, i);
             }
             PAR_FOR(T, i, 0, m) r_out[(size_t)k * m + i] = r[i];
         }

@@ -496,11 +496,13 @@ SPMD_HD inline void transform_cols(const Work &W, int n, int mg, int H, const do
                 }
                 SPMD_UNROLL
                 for (int q = 0; q < 6; ++q) {
+                    double e[NC];                          // the row of e first, in one go: one wait instead of NC
+                    SPMD_UNROLL
+                    for (int c = 0; c < NC; ++c) e[c] = er[c];
                     SPMD_UNROLL
                     for (int c = 0; c < NC; ++c) {
-                        const double e = er[c];
                         SPMD_UNROLL
-                        for (int r = 0; r < R; ++r) acc[r][c] = acc[r][c] + gk[r][q] * e;
+                        for (int r = 0; r < R; ++r) acc[r][c] = acc[r][c] + gk[r][q] * e[c];
                     }
                     er += n - (6 * kb + q) - 1;
                 }
@@ -761,6 +763,27 @@ SPMD_HD int lsq(const Team &T, const Work &W, int H, const double *g, const doub
 #undef EO
 }
 
+// Column i of the structured dc/dx times r, rows in ascending order: the position row of state j + 1, its velocity
+// row, then the position rows of states j + 2 .. H (i = 6 j + a).  Loads are issued eight ahead of the ordered sum.
+SPMD_HD inline double jac_column_dot(int H, const double *nz, const double *r, int i)
+{
+    const int j = i / 6, a = i % 6;
+    const double *pos = nz + 6 * H + 6 * (j * H - (j * (j - 1)) / 2 - j - 1) + a;       // pos[6 kk] = entry of state kk
+    double t = 0.0;
+    t = t + pos[6 * (j + 1)] * r[12 * (j + 1) + a];
+    t = t + nz[i] * r[12 * (j + 1) + 6 + a];
+    int kk = j + 2;
+    for (; kk + 7 <= H; kk += 8) {
+        double nv[8], rv[8];
+        SPMD_UNROLL
+        for (int q = 0; q < 8; ++q) { nv[q] = pos[6 * (kk + q)]; rv[q] = r[12 * (kk + q) + a]; }
+        SPMD_UNROLL
+        for (int q = 0; q < 8; ++q) t = t + nv[q] * rv[q];
+    }
+    for (; kk <= H; ++kk) t = t + pos[6 * kk] * r[12 * kk + a];
+    return t;
+}
+
 // Rank-one update of the LDL' factorisation a (packed by columns) with z and sigma; w is work (Fletcher &
 // Powell's composite-t method as in slsqp_core.c's ldl).  The serial text interleaves three things per column i:
 // the pivot v(i) = z(i) after the earlier columns' eliminations, the scalars (t, alpha, beta, gamma) and the update of
@@ -866,14 +889,7 @@ SPMD_HD void bfgs_update(const Team &T, const Work &W, int H, double *l, const d
     const int n = 6 * H;
     double *vold = W.acc;
     PAR_FOR(T, i, 0, n) {
-        const int j = i / 6, a = i % 6;
-        const int tri = j * H - (j * (j - 1)) / 2 - j - 1;
-        double t = 0.0;                                   // column i of dc/dx times r, rows in ascending order
-        for (int kk = j + 1; kk <= H; ++kk) {
-            t = t + nz[6 * H + 6 * (tri + kk) + a] * r[12 * kk + a];
-            if (kk == j + 1) t = t + nz[i] * r[12 * (j + 1) + 6 + a];
-        }
-        u[i] = g[i] - t - v[i];
+        u[i] = g[i] - jac_column_dot(H, nz, r, i) - v[i];
     }
     T.sync();
     PAR_FOR(T, i, 0, n) {
