@@ -319,6 +319,34 @@ def test_closed_loop_through_the_pool_equals_one_process():
     np.testing.assert_array_equal(many.converged, one.converged)
 
 
+def test_device_qp_driver_hands_inconsistent_linearisations_to_the_host():
+    """A joint that starts beyond its limit makes a constraint row negative with a zero gradient: the linearised QP
+    is inconsistent (mode 4) and Kraft's body switches to the augmented problem, which the device does not solve.
+    Such problems are marked and solved again by the host-only driver; the rest of the batch is untouched and every
+    result equals the host-only driver's."""
+    from helpers import host_scenarios
+    from mpc_amd.batch import MpcContext
+    from mpc_amd.native_solver import DeviceQpSLSQP, NativeBatchedSLSQP
+    from mpc_amd.scenarios import to_device
+
+    mp = MpcParams.reference_yaml_defaults(horizon=3)
+    N = 12
+    ctx = MpcContext(mp, N, 0)
+    _, hs = host_scenarios(mp, N, motion="angular", cfg_id=23)
+    bad = [2, 7]
+    hs.state0[bad, 0] = mp.q_limit + 0.2
+    sc, _ = to_device(ctx, hs)
+    with NativeBatchedSLSQP(ctx, threads=2) as host:
+        one = host.solve(sc, hs.x)
+    with DeviceQpSLSQP(ctx, threads=2) as dev:
+        two = dev.solve(sc, hs.x)
+    assert two.n_host_fallback == len(bad)
+    np.testing.assert_array_equal(two.status, one.status)
+    np.testing.assert_array_equal(two.nit, one.nit)
+    np.testing.assert_array_equal(two.x, one.x)
+    np.testing.assert_array_equal(two.fun, one.fun)
+
+
 def test_closed_loop_with_the_qp_on_the_device_equals_one_process():
     """Six ticks of 24 controllers at H=20 and of 160 at H=3 (two lanes): with the BFGS update and the QP of every
     iteration on the GPU the trajectories are those of scipy's own core, bit for bit (warm starts, EMA, clip
