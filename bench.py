@@ -281,7 +281,7 @@ def main():
     ap.add_argument("--motion", default="linear", choices=["linear", "angular"])
     ap.add_argument("--algo", type=int, default=_ffi.ALGO_AUTO)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--solve-sample", type=int, default=16384,
+    ap.add_argument("--solve-sample", type=int, default=65536,
                     help="scenarios per GPU in the bounded solves/s sample (0: skip)")
     ap.add_argument("--solve-workers", type=int, default=0, help="SLSQP host threads per GPU (0: host cores - 1)")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
