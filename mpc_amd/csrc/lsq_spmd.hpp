@@ -59,7 +59,7 @@ struct Work {
     double *xs;    // [n]
     double *sc;    // [16]  scalars broadcast from thread 0
     double *redv;  // = acc
-    int *redi;     // [team size]
+    int *redi;     // [max(team size, n1)]: NNLS's reduction; afterwards the final set, sorted
     int *idx;      // [mg]
     int *isc;      // [16]
 };
@@ -72,7 +72,10 @@ SPMD_HD inline size_t small_doubles(int n, int m, int team)
     return (size_t)n * n1 / 2 + 1 + n + accn + n1 + n1 + mg + mg + n1 + n + 16;
 }
 SPMD_HD inline size_t work_doubles(int n, int m, int team) { return big_doubles(n, m) + small_doubles(n, m, team); }
-SPMD_HD inline size_t work_ints(int n, int m, int team) { return (size_t)team + (size_t)m + 2 * (size_t)n + 16; }
+SPMD_HD inline size_t work_ints(int n, int m, int team)
+{
+    return (size_t)(team > n + 1 ? team : n + 1) + (size_t)m + 2 * (size_t)n + 16;
+}
 
 SPMD_HD inline Work carve(double *big, double *d, int *i, int n, int m, int team)
 {
@@ -91,7 +94,7 @@ SPMD_HD inline Work carve(double *big, double *d, int *i, int n, int m, int team
     W.xs = d;           d += n;
     W.sc = d;
     W.redv = W.acc;
-    W.redi = i;         i += team;
+    W.redi = i;         i += team > n + 1 ? team : n + 1;
     W.idx = i;          i += mg;
     W.isc = i;
     return W;
@@ -426,6 +429,7 @@ SPMD_HD int nnls(const Team &T, const Work &W, int mrow, int ncol, int mg, doubl
     if (T.tid() == 0) {
         const int k = npp1 < m ? npp1 : m;
         *rnorm_out = nrm2(m - nsetp, &b[k - 1], 1);
+        W.isc[11] = nsetp;                                 // index[0..nsetp) is the final set
     }
     if (npp1 > m) PAR_FOR(T, i, 0, ncol) w[i] = 0.0;
     T.sync();
@@ -695,22 +699,25 @@ SPMD_HD int lsq(const Team &T, const Work &W, int H, const double *g, const doub
             transform_rows<1>(W, H, rows, cvals, nz, lo, hi, dst);
         }
     T.sync();
-    // ---- column sums against the NNLS solution (column n is h): only the rows in the final set contribute
+    // ---- column sums against the NNLS solution (column n is h): only the rows in the final set contribute, in
+    //      ascending order as in the serial sums over all rows (every other entry of the solution is an exact zero)
+    const int nset = W.isc[11];
+    if (T.tid() == 0) {                                    // the set, sorted (it is short: insertion sort)
+        for (int q = 0; q < nset; ++q) {
+            const int v = W.idx[q] - 1;
+            int pos = q;
+            while (pos > 0 && W.redi[pos - 1] > v) { W.redi[pos] = W.redi[pos - 1]; --pos; }
+            W.redi[pos] = v;
+        }
+    }
+    T.sync();
     PAR_FOR(T, j, 0, n + 1) {
         const double *gj = W.G + (size_t)j * mg;
         double t = 0.0;
-        int i = 0;
-        for (; i + 8 <= mg; i += 8) {                      // rows outside the set: not stored, not read
-            double xv[8];
-            SPMD_UNROLL
-            for (int q = 0; q < 8; ++q) xv[q] = W.xn[i + q];
-            SPMD_UNROLL
-            for (int q = 0; q < 8; ++q)
-                if (xv[q] != 0.0) t = t + gj[i + q] * xv[q];
-        }
-        for (; i < mg; ++i) {
+        for (int q = 0; q < nset; ++q) {
+            const int i = W.redi[q];
             const double xi = W.xn[i];
-            if (xi != 0.0) t = t + gj[i] * xi;
+            if (xi != 0.0) t = t + gj[i] * xi;             // rows outside the set: not stored, not read
         }
         W.zz[j] = t;
     }
