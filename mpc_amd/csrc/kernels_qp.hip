@@ -16,6 +16,13 @@ struct HipTeam {
     __device__ int tid() const { return (int)threadIdx.x; }
     __device__ int size() const { return (int)blockDim.x; }
     __device__ void sync() const { __syncthreads(); }
+    // orders the LDS traffic of ONE wavefront (threads 0..63 of the team): its earlier writes are done before its later
+    // reads; no other wavefront is waited for
+    __device__ void wave_sync() const
+    {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
 };
 
 extern __shared__ double qp_lds[];

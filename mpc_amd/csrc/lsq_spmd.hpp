@@ -37,6 +37,7 @@ struct SerialTeam {
     SPMD_HD int tid() const { return 0; }
     SPMD_HD int size() const { return 1; }
     SPMD_HD void sync() const {}
+    SPMD_HD void wave_sync() const {}
 };
 
 #define PAR_FOR(T, i, lo, hi) for (int i = (lo) + (T).tid(); i < (hi); i += (T).size())
@@ -739,23 +740,23 @@ SPMD_HD int lsq(const Team &T, const Work &W, int H, const double *g, const doub
     //      chain (thread 0); the products are formed by the team first.
     PAR_FOR(T, i, 0, n) W.xs[i] = W.xs[i] + 1.0 * W.ff[i];
     T.sync();
-    // Row i needs the products e(i, j) x(j), j > i, added in ascending j.  All but the first are ready one row
-    // earlier, so while thread 0 adds up row i the team already forms row i - 1's products for j > i (two
-    // buffers, used alternately); thread 0 only adds the product with the x(i + 1) it has just finished.
-    for (int i = n - 1; i >= 0; --i) {
-        const double *er = W.E + EO(i) - i;                // er[j] = e(i, j)
-        double *mine = (i & 1) ? W.piv : W.zz, *next = (i & 1) ? W.zz : W.piv;
-        if (T.tid() == 0) {
-            double t = 0.0;
-            if (i + 1 < n) {
-                t = t + er[i + 1] * W.xs[i + 1];
-                t = sum_in_order(t, mine + i + 2, n - i - 2);
+    // Row i needs the products e(i, j) x(j), j > i, added in ascending j.  The whole recurrence runs on the team's
+    // first wavefront alone (up to 64 threads form the products, its first thread adds them up): what one wavefront
+    // writes to LDS it reads back in program order, so no workgroup barrier separates the 2n steps; the other
+    // wavefronts wait at the one barrier after the loop.
+    {
+        const int wl = T.size() < 64 ? T.size() : 64;
+        if (T.tid() < wl) {
+            for (int i = n - 1; i >= 0; --i) {
+                const double *er = W.E + EO(i) - i;        // er[j] = e(i, j)
+                for (int j = i + 1 + T.tid(); j < n; j += wl) W.piv[j] = er[j] * W.xs[j];
+                T.wave_sync();
+                if (T.tid() == 0) {
+                    const double t = sum_in_order(0.0, W.piv + i + 1, n - i - 1);
+                    W.xs[i] = (W.xs[i] - t) / er[i];
+                }
+                T.wave_sync();
             }
-            W.xs[i] = (W.xs[i] - t) / er[i];
-        }
-        if (i > 0) {
-            const double *eu = W.E + EO(i - 1) - (i - 1);  // eu[j] = e(i - 1, j)
-            PAR_FOR(T, j, i + 1, n) next[j] = eu[j] * W.xs[j];
         }
         T.sync();
     }
