@@ -409,6 +409,13 @@ class _DeviceQpLane:
         self.batch.close()
 
 
+def active_lanes(count: int, lanes: int, lane_capacity: int, min_per_lane: int) -> int:
+    """How many of a DeviceQpSLSQP's lanes a batch of `count` problems is split over: one per `min_per_lane`
+    problems (more only add launches and host threads), but enough for every part to fit its lane."""
+    k = max(1, min(lanes, count // max(1, min_per_lane)))
+    return max(k, (count + lane_capacity - 1) // lane_capacity)
+
+
 class DeviceQpSLSQP:
     """Batched SLSQP with the quadratic subproblems on the GPU.
 
@@ -458,9 +465,7 @@ class DeviceQpSLSQP:
         caller = torch.cuda.current_stream(ctx.device)
         for lane in self.lanes:
             lane.stream.wait_stream(caller)              # the scenarios were written on the caller's stream
-        lane_cap = self.lanes[0].cap
-        k = max(1, min(len(self.lanes), N // self.min_per_lane))
-        k = max(k, (N + lane_cap - 1) // lane_cap)
+        k = active_lanes(N, len(self.lanes), self.lanes[0].cap, self.min_per_lane)
         if k == 1:
             parts = [self.lanes[0].solve(sc, x0)]
         else:

@@ -79,3 +79,18 @@ def test_batched_kinematic_predictor_equals_per_controller_predictor():
                 row = np.concatenate([want[k]["position"], want[k]["orientation"], want[k]["linear_velocity"],
                                       want[k]["angular_velocity"]])
                 np.testing.assert_array_equal(got[j, k], row)
+
+
+def test_device_qp_driver_lane_choice():
+    """One lane per ~min_per_lane problems, never more than there are, always enough for the parts to fit."""
+    from mpc_amd.native_solver import active_lanes
+
+    assert active_lanes(9, 4, 64, 32) == 1
+    assert active_lanes(150, 4, 64, 32) == 4
+    assert active_lanes(100, 4, 64, 32) == 3
+    assert active_lanes(4095, 4, 2048, 2048) == 2          # one lane would not hold it
+    assert active_lanes(65536, 4, 16384, 2048) == 4
+    assert active_lanes(3000, 4, 16384, 2048) == 1
+    for count in range(1, 700, 7):
+        k = active_lanes(count, 4, 175, 50)
+        assert 1 <= k <= 4 and (count + k - 1) // k <= 175
