@@ -6,8 +6,11 @@
 #include "lsq_spmd.hpp"
 #include "mpc_kernels.hpp"
 
+// Teams of 256 threads, two per CU (LDS), hence two waves per SIMD and 256 VGPRs per wave: the row transform keeps
+// its 2 x 12 accumulators, the row's earlier entries and a row of e in registers without spilling (with 512-thread
+// teams, 128 VGPRs per wave, it spilled ~140 registers and whole solves were 8 % slower).
 #ifndef MPC_QP_WAVES
-#define MPC_QP_WAVES 4
+#define MPC_QP_WAVES 2
 #endif
 
 namespace {

@@ -55,7 +55,7 @@ hipError_t launch_prepare_tick(const mpc_params &P, int N, const double (&dyn)[6
 // SLSQP's QP subproblem, one workgroup per problem (kernels_qp.hip).  `teams` workgroups share the batch;
 // work / iwork hold teams * qp_work_doubles(H) doubles / teams * qp_work_ints(H) ints.
 #ifndef MPC_QP_THREADS
-#define MPC_QP_THREADS 512
+#define MPC_QP_THREADS 256
 #endif
 constexpr int kQpThreads = MPC_QP_THREADS;
 constexpr size_t kQpLdsLimit = 160 * 1024;   // LDS of one CU (gfx950)
