@@ -157,16 +157,16 @@ SPMD_HD int nnls(const Team &T, const Work &W, int mrow, int ncol, int mg, doubl
             const int j = index[t];
             double s = 0.0;
             // a * (+-0.0) added to a sum that is never -0.0 changes nothing: rows where b is zero are not read.
-            // Eight rows at a time, loads first, so that a thread does not wait for each load in turn.
+            // Sixteen rows at a time, loads first, so that a thread does not wait for each load in turn.
             int r = npp1;
-            for (; r + 7 <= m; r += 8) {
-                double bv[8], av[8];
+            for (; r + 15 <= m; r += 16) {
+                double bv[16], av[16];
                 SPMD_UNROLL
-                for (int q = 0; q < 8; ++q) bv[q] = b[r - 1 + q];
+                for (int q = 0; q < 16; ++q) bv[q] = b[r - 1 + q];
                 SPMD_UNROLL
-                for (int q = 0; q < 8; ++q) av[q] = bv[q] != 0.0 ? AT(r + q, j) : 0.0;
+                for (int q = 0; q < 16; ++q) av[q] = bv[q] != 0.0 ? AT(r + q, j) : 0.0;
                 SPMD_UNROLL
-                for (int q = 0; q < 8; ++q)
+                for (int q = 0; q < 16; ++q)
                     if (bv[q] != 0.0) s = s + av[q] * bv[q];
             }
             for (; r <= m; ++r) {
@@ -289,24 +289,24 @@ SPMD_HD int nnls(const Team &T, const Work &W, int mrow, int ncol, int mg, doubl
                     const int jj = index[t];
                     double sm = AT(nsetp, jj) * up;
                     int r = npp1;
-                    for (; r + 7 <= m; r += 8) {                // loads first, sums in order
-                        double av[8], pv8[8];
+                    for (; r + 15 <= m; r += 16) {              // loads first, sums in order
+                        double av[16], pv8[16];
                         SPMD_UNROLL
-                        for (int q = 0; q < 8; ++q) { av[q] = AT(r + q, jj); pv8[q] = W.piv[r - 1 + q]; }
+                        for (int q = 0; q < 16; ++q) { av[q] = AT(r + q, jj); pv8[q] = W.piv[r - 1 + q]; }
                         SPMD_UNROLL
-                        for (int q = 0; q < 8; ++q) sm = sm + av[q] * pv8[q];
+                        for (int q = 0; q < 16; ++q) sm = sm + av[q] * pv8[q];
                     }
                     for (; r <= m; ++r) sm = sm + AT(r, jj) * W.piv[r - 1];
                     if (sm != 0.0) {
                         sm = sm * bq;
                         AT(nsetp, jj) = AT(nsetp, jj) + sm * up;
                         r = npp1;
-                        for (; r + 7 <= m; r += 8) {
-                            double av[8], pv8[8];
+                        for (; r + 15 <= m; r += 16) {
+                            double av[16], pv8[16];
                             SPMD_UNROLL
-                            for (int q = 0; q < 8; ++q) { av[q] = AT(r + q, jj); pv8[q] = W.piv[r - 1 + q]; }
+                            for (int q = 0; q < 16; ++q) { av[q] = AT(r + q, jj); pv8[q] = W.piv[r - 1 + q]; }
                             SPMD_UNROLL
-                            for (int q = 0; q < 8; ++q) AT(r + q, jj) = av[q] + sm * pv8[q];
+                            for (int q = 0; q < 16; ++q) AT(r + q, jj) = av[q] + sm * pv8[q];
                         }
                         for (; r <= m; ++r) AT(r, jj) = AT(r, jj) + sm * W.piv[r - 1];
                     }
