@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MPC_AMD_ABI_VERSION 5
+#define MPC_AMD_ABI_VERSION 6
 #define MPC_MAX_HORIZON 255
 
 typedef enum mpc_status {
@@ -119,6 +119,19 @@ int mpc_eval(mpc_ctx *ctx, const mpc_scenarios *sc, const double *x, double *cos
  *   layout the Fortran core of SLSQP consumes (a(la, n+1), SLSQP:509).  grad/con/con_jac may be NULL. */
 int mpc_eval_fd(mpc_ctx *ctx, const mpc_scenarios *sc, const double *x, double *cost, double *grad,
                 double *con, double *con_jac, void *stream);
+
+/* mpc_eval_fd for callers that cannot allocate (code under HIP graph capture, tight serving loops, harnesses
+ * that forbid hipMalloc).  NO COUNTERPART IN THE REFERENCE: same arguments, same outputs, always the
+ * MPC_ALGO_ROLLOUT kernels (bit-identical to mpc_eval_fd on a context whose algo is MPC_ALGO_ROLLOUT; any 6R
+ * DH table), but the per-rollout costs between its two kernels live in a file-scope device array of
+ * MPC_STATIC_SCRATCH_DOUBLES doubles (16 MiB, held by every GPU the library runs on until the process ends)
+ * instead of a context allocation.  The call itself allocates and frees nothing.  Limit: count * (6H + 1) <=
+ * MPC_STATIC_SCRATCH_DOUBLES (17,331 scenarios at H = 20, 3,489 at H = 100), MPC_ERR_INVALID_ARG beyond it.
+ * All calls on one GPU share that GPU's array: calls that overlap on one GPU (two streams, two contexts, two
+ * threads) race; nothing in it has to start at zero (each launch writes every entry it reads). */
+#define MPC_STATIC_SCRATCH_DOUBLES (2 * 1024 * 1024)
+int mpc_eval_fd_static(mpc_ctx *ctx, const mpc_scenarios *sc, const double *x, double *cost, double *grad,
+                       double *con, double *con_jac, void *stream);
 
 /* Structured form of the same forward-difference dc/dx.  Column x_{6j+a} (control of joint a at step j)
  * only reaches the rows of joint a: the velocity row of state j+1 and the position rows of states

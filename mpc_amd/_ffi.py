@@ -11,12 +11,13 @@ LIB_PATH = os.environ.get("MPC_AMD_LIB") or os.path.join(_HERE, "libmpc_amd.so")
 MPC_OK = 0
 ALGO_AUTO, ALGO_ROLLOUT, ALGO_PREFIX = 0, 1, 2
 MAX_HORIZON = 255
-ABI_VERSION = 5
+ABI_VERSION = 6
+STATIC_SCRATCH_DOUBLES = 2 * 1024 * 1024
 
 EXPORTS = (
     "mpc_abi_version", "mpc_ctx_create", "mpc_ctx_destroy", "mpc_set_params", "mpc_eval", "mpc_eval_fd",
     "mpc_jacobian", "mpc_fk", "mpc_predict_base_dynamic", "mpc_prepare_tick", "mpc_qp_solve", "mpc_qp_step", "mpc_gather_scenarios", "mpc_jacobian_nz_count", "mpc_eval_fd_nz",
-    "mpc_expand_jacobian", "mpc_last_error",
+    "mpc_expand_jacobian", "mpc_last_error", "mpc_eval_fd_static",
 )
 
 
@@ -75,6 +76,8 @@ def load():
     L.mpc_eval.argtypes = [vp, C.POINTER(MpcScenariosC), vp, vp, vp, vp]
     L.mpc_eval_fd.restype = ip
     L.mpc_eval_fd.argtypes = [vp, C.POINTER(MpcScenariosC), vp, vp, vp, vp, vp, vp]
+    L.mpc_eval_fd_static.restype = ip
+    L.mpc_eval_fd_static.argtypes = [vp, C.POINTER(MpcScenariosC), vp, vp, vp, vp, vp, vp]
     L.mpc_jacobian.restype = ip
     L.mpc_jacobian.argtypes = [vp, ip, vp, vp, vp]
     L.mpc_fk.restype = ip

@@ -181,6 +181,21 @@ class MpcContext:
                                                     self._stream()))
         return EvalResult(cost, grad, con, jac)
 
+    def eval_fd_static(self, sc: ScenarioBatch, x: torch.Tensor, out: EvalResult) -> EvalResult:
+        """mpc_eval_fd_static (include/mpc_amd.h): eval_fd for callers that cannot allocate.  Every output
+        buffer comes from the caller (``out`` must hold cost, grad, con and con_jac); the library keeps the
+        per-rollout costs in its static device array, so nothing is allocated on either side of the boundary.
+        At most ``_ffi.STATIC_SCRATCH_DOUBLES // (n + 1)`` scenarios; calls on one GPU must not overlap."""
+        N = sc.count
+        scc = self._scen_c(sc)
+        xp = self._chk(x, (N, self.n), "x")
+        cp0 = self._chk(out.cost, (N,), "cost")
+        gp = self._chk(out.grad, (N, self.n), "grad", optional=True)
+        cp = self._chk(out.con, (N, self.m), "con", optional=True)
+        jp = self._chk(out.con_jac, (N, self.n, self.m), "con_jac", optional=True)
+        _ffi.check(self._ctx, self._lib.mpc_eval_fd_static(self._ctx, C.byref(scc), xp, cp0, gp, cp, jp, self._stream()))
+        return out
+
     @property
     def nz_count(self) -> int:
         return int(self._lib.mpc_jacobian_nz_count(self.H))

@@ -4,6 +4,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <new>
 
 #include <hip/hip_runtime.h>
@@ -25,12 +26,42 @@ struct mpc_ctx {
     double *d_qp_work = nullptr;  // mpc_qp_solve: workspace of the resident workgroups (allocated on first use)
     int *d_qp_iwork = nullptr;
     int qp_teams = 0;
+    double *d_static = nullptr;   // this device's copy of the file-scope `scratch` array (mpc_eval_fd_static)
     char err[512] = {0};
 };
+
+// mpc_eval_fd_static: the per-rollout costs of MPC_ALGO_ROLLOUT (what mpc_ctx_create otherwise allocates as
+// d_fvals) live in this file-scope device array instead, so that entry point allocates nothing.  The name is
+// a host-side stand-in: its device address is taken once per device (static_scratch_for) and only that
+// pointer is ever handed to a kernel.  Each GPU the library runs on holds its own 16 MiB copy.
+static __device__ __align__(256) double scratch[MPC_STATIC_SCRATCH_DOUBLES];
 
 namespace {
 
 thread_local char g_err[512] = {0};
+
+constexpr int kMaxDevices = 64;
+std::mutex g_scratch_mutex;
+double *g_scratch_ptr[kMaxDevices] = {nullptr};
+
+// Device address of `scratch` on `device`; resolved once per device, with that device current.
+hipError_t static_scratch_for(int device, double **out)
+{
+    *out = nullptr;
+    if (device < 0 || device >= kMaxDevices) return hipErrorInvalidDevice;
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_ptr[device]) {
+        hipError_t e = hipSetDevice(device);
+        if (e != hipSuccess) return e;
+        double *ptr = nullptr;
+        e = hipGetSymbolAddress(reinterpret_cast<void **>(&ptr), HIP_SYMBOL(scratch));
+        if (e != hipSuccess) return e;
+        if (!ptr) return hipErrorInvalidSymbol;
+        g_scratch_ptr[device] = ptr;
+    }
+    *out = g_scratch_ptr[device];
+    return hipSuccess;
+}
 
 constexpr size_t kWorkCapBytes = size_t(2) << 30;
 
@@ -108,6 +139,7 @@ int mpc_ctx_create(int device, int horizon, int max_scenarios, mpc_ctx **out)
     ctx->horizon = horizon;
     ctx->max_scenarios = max_scenarios;
     hipError_t e = hipSetDevice(device);
+    if (e == hipSuccess) e = static_scratch_for(device, &ctx->d_static);   // set-up: once per device
     if (e == hipSuccess) e = hipMalloc(&ctx->d_decay, sizeof(double) * (size_t)horizon);
     if (e == hipSuccess)
         e = hipMalloc(&ctx->d_fvals, sizeof(double) * (size_t)max_scenarios * (size_t)(6 * horizon + 1));
@@ -225,6 +257,31 @@ int mpc_eval_fd(mpc_ctx *ctx, const mpc_scenarios *sc, const double *x, double *
     const int n = 6 * ctx->horizon;
     MPC_HIP(ctx, mpck::launch_rollout(ctx->params, ctx->d_decay, *sc, x, ctx->d_fvals, n + 1, con, con_jac, n, st));
     MPC_HIP(ctx, mpck::launch_fd_finalize(ctx->params, sc->count, x, ctx->d_fvals, cost, grad, st));
+    return MPC_OK;
+}
+
+int mpc_eval_fd_static(mpc_ctx *ctx, const mpc_scenarios *sc, const double *x, double *cost, double *grad, double *con,
+                       double *con_jac, void *stream)
+{
+    int rc = check_ready(ctx);
+    if (rc) return rc;
+    rc = check_scenarios(ctx, sc, x);
+    if (rc) return rc;
+    if (sc->count == 0) return MPC_OK;
+    if (!cost) return fail(ctx, MPC_ERR_INVALID_ARG, "cost is NULL");
+    const int n = 6 * ctx->horizon;
+    if ((size_t)sc->count * (size_t)(n + 1) > (size_t)MPC_STATIC_SCRATCH_DOUBLES)
+        return fail(ctx, MPC_ERR_INVALID_ARG,
+                    "mpc_eval_fd_static: %d scenarios x (6H+1 = %d) rollout costs exceed the static scratch of %d doubles "
+                    "(at most %d scenarios at this horizon)", sc->count, n + 1, (int)MPC_STATIC_SCRATCH_DOUBLES,
+                    (int)(MPC_STATIC_SCRATCH_DOUBLES / (n + 1)));
+    double *fvals = ctx->d_static;   // the device address, never the array's name
+    if (!fvals) return fail(ctx, MPC_ERR_HIP, "static scratch was not resolved on device %d", ctx->device);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    MPC_HIP(ctx, hipSetDevice(ctx->device));
+    // every fvals[s][0..n] that fd_finalize reads is written by this launch: nothing has to start at zero
+    MPC_HIP(ctx, mpck::launch_rollout(ctx->params, ctx->d_decay, *sc, x, fvals, n + 1, con, con_jac, n, st));
+    MPC_HIP(ctx, mpck::launch_fd_finalize(ctx->params, sc->count, x, fvals, cost, grad, st));
     return MPC_OK;
 }
 
