@@ -63,6 +63,71 @@ def all_gather(dist, out, t):
         dist.all_gather_into_tensor(out, t)
 
 
+def launch_ranks(gpus: int, argv) -> int:
+    """`python bench.py --gpus N` without a launcher around it: start the N ranks as CHILD processes
+    (torch.distributed.run, one rank per GPU, rendezvous on 127.0.0.1) before this process has made any GPU
+    call, relay rank 0's JSON line, and return the children's exit status.  The parent never initialises the
+    GPU and never re-executes itself."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ)
+    if "OMP_NUM_THREADS" not in env:          # torch.distributed.run would pin every rank to ONE host thread
+        from mpc_amd.pool import host_core_budget
+
+        env["OMP_NUM_THREADS"] = str(host_core_budget(gpus))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    lines = 0
+    for line in proc.stdout:
+        if line.lstrip().startswith("{") and '"metric"' in line:
+            print(line.rstrip("\n"), flush=True)
+            lines += 1
+        else:                                  # anything else a rank printed goes to stderr: stdout carries one line
+            print(line.rstrip("\n"), file=sys.stderr, flush=True)
+    rc = proc.wait()
+    if rc == 0 and lines != 1:
+        print(f"bench.py: the ranks exited cleanly but printed {lines} result lines", file=sys.stderr)
+        return 1
+    return rc
+
+
+def solve_result_rows(control: np.ndarray, last, rows: np.ndarray) -> np.ndarray:
+    """Per-scenario results of one batched tick, [count, 9] = [f*, u0(6), nit, status]:
+    what compute_control returns (ur_mpc.py:205-237) plus the optimiser's final cost, iteration count and exit
+    mode.  Controllers that took the early exit (ur_mpc.py:108) have f* = 0, nit = 0, status = -1."""
+    out = np.zeros((control.shape[0], 9))
+    out[:, 1:7] = control
+    out[:, 8] = -1.0
+    if last is not None and len(rows):
+        out[rows, 0] = last.fun
+        out[rows, 7] = last.nit
+        out[rows, 8] = last.status
+    return out
+
+
+def gather_result_rows(dist, local: np.ndarray, world: int, rank: int, device) -> np.ndarray:
+    """The one exchange of the job: every rank's [count, 9] rows -> the [world*count, 9] table in rank order on
+    every rank (RCCL all_gather over xGMI; gloo through the host in the rehearsal modes).  Checks that this
+    rank's block of the table is bit for bit what it sent."""
+    if dist is None:
+        return local
+    from mpc_amd.sharding import gather_rows
+
+    t = torch.as_tensor(np.ascontiguousarray(local))
+    if not _HOST_COLLECTIVES:
+        t = t.to(device)
+    full = gather_rows(t, world * local.shape[0]).cpu().numpy()
+    c = local.shape[0]
+    if not np.array_equal(full[rank * c:(rank + 1) * c], local):
+        raise RuntimeError("gathered solve results differ from what this rank contributed")
+    return full
+
+
 def algorithmic_flops(H: int) -> float:
     """full rollouts, one fused cost+constraint rollout per perturbation."""
     return (1 + 6 * H) * (745 * H + 600 + 30 * (H + 1))
@@ -203,7 +268,7 @@ def solve_rate(ctx, mp, sample, threads, rank, world, dist, device_qp=True):
         return bool(t.item() > 0.5)
 
     count = min(sample, ctx.max_scenarios)
-    native, err, hs, bm, dt = None, None, None, None, 0.0
+    native, err, hs, bm, dt, table = None, None, None, None, 0.0, None
     try:
         hs = make_scenarios(mp, DeviceKinematics(ctx), count, motion="angular", cfg_id=3, goal_jitter=0.0,
                             first=rank * count)
@@ -221,7 +286,8 @@ def solve_rate(ctx, mp, sample, threads, rank, world, dist, device_qp=True):
         try:
             bm = BatchedMPC(ctx, solver=native)
             t0 = time.perf_counter()
-            bm.compute_control(hs.q0, hs.state0[:, 12:18], hs.target, hs.base)
+            u = bm.compute_control(hs.q0, hs.state0[:, 12:18], hs.target, hs.base)
+            table = gather_result_rows(dist, solve_result_rows(u, bm.last, bm.last_rows), world, rank, ctx.device)
             dt = time.perf_counter() - t0
         except Exception as exc:  # noqa: BLE001
             err = repr(exc)
@@ -248,6 +314,10 @@ def solve_rate(ctx, mp, sample, threads, rank, world, dist, device_qp=True):
                      f"(libmpc_slsqp.so) on {threads} host threads per GPU",
            "seconds": dt_all, "mean_iterations": float(r.nit.mean()), "rounds_rank0": r.rounds,
            "rank0_core_seconds_busiest_thread": r.t_core, "rank0_seconds_serving_from_gpu": r.t_serve}
+    out["gathered"] = {"rows": int(table.shape[0]), "columns": "f*, u0[6], nit, status",
+                       "converged_rows": int((table[:, 8] == 0).sum()), "early_exit_rows": int((table[:, 8] == -1).sum()),
+                       "sum_abs_u0": float(np.abs(table[:, 1:7]).sum()),
+                       "how": "one all_gather of every rank's [count, 9] block, inside the timed region"}
     if device_qp:
         out["rank0_qp_subproblems_on_gpu"] = int(r.n_qp)
         out["rank0_solved_again_on_host"] = int(r.n_host_fallback)
@@ -271,6 +341,41 @@ def pool_solve_rate(ctx, mp, per_worker, workers):
             "sample": f"{int(hs.active.sum())} scenarios, scipy's compiled SLSQP core in {workers} worker processes"}
 
 
+def rehearse_launch(args, world):
+    """No GPU: the ranks rendezvous over gloo, each contributes synthetic [count, 9] rows that depend only on
+    the GLOBAL scenario index, the table is gathered as in the solves leg and rank 0 prints a line of the usual
+    shape.  Exercises launch_ranks, the rank/shard bookkeeping and gather_result_rows; measures nothing."""
+    global _HOST_COLLECTIVES
+    _HOST_COLLECTIVES = True
+    rank = int(os.environ.get("RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.init_process_group("gloo")
+    if os.environ.get("MPC_BENCH_REHEARSE_FAIL_RANK") == str(rank):     # test hook: one rank dies before the gather
+        sys.exit(f"rank {rank}: failing on request")
+    S = min(args.scenarios, 1000)
+    gidx = rank * S + np.arange(S)
+    local = np.stack([np.sin(gidx * (k + 1.0)) for k in range(9)], axis=1)
+    t0 = time.perf_counter()
+    table = gather_result_rows(dist, local, world, rank, None)
+    dt = time.perf_counter() - t0
+    want = np.stack([np.sin(np.arange(world * S) * (k + 1.0)) for k in range(9)], axis=1)
+    assert np.array_equal(table, want), "gathered table is not the single-process table"
+    if rank == 0:
+        print(json.dumps({"metric": "launch rehearsal (no GPU, numbers mean nothing)", "value": 0.0, "unit": "evals/s",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt * 1e3,
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+                          "data": "synthetic", "config": {"workload": "rehearsal", "scenarios_per_gpu": S,
+                                                          "parallelism": f"scenario-dp{world}"},
+                          "solves": {"gathered": {"rows": int(table.shape[0]), "checksum": float(table.sum())},
+                                     "host_threads_per_gpu": int(os.environ.get("OMP_NUM_THREADS", "0"))}}), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -289,9 +394,22 @@ def main():
                          "multi-rank code path on a one-GPU box (the numbers mean nothing)")
     ap.add_argument("--only-main", action="store_true",
                     help="run only the timed loop (profiling: every dispatch of the kernel is the benchmark's)")
+    ap.add_argument("--rehearse-launch", action="store_true",
+                    help="development / CPU test only: walk the launch + gather path with NO GPU (gloo, synthetic "
+                         "per-scenario rows); prints a line whose numbers mean nothing")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no launcher around us: start the ranks ourselves, before anything here touches the GPU
+        if not (args.rehearse_on_one_gpu or args.rehearse_launch) and torch.cuda.device_count() < args.gpus:
+            sys.exit(f"bench.py --gpus {args.gpus}: only {torch.cuda.device_count()} GPUs visible")
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if "WORLD_SIZE" in os.environ and world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started {world} ranks")
+    if args.rehearse_launch:
+        return rehearse_launch(args, world)
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():

@@ -43,9 +43,8 @@ def run_closed_loop(ctx: MpcContext, q0: np.ndarray, motion: str, amplitude: np.
         base = platform_state(motion, amplitude, phase, tick * p.dt)
         u = bm.compute_control(q, ee, target, base)
         ok = np.ones(N, dtype=bool)
-        if bm.last is not None:
-            active = ~((np.linalg.norm(base[:, 6:9], axis=1) < 0.01) & (np.linalg.norm(base[:, 9:12], axis=1) < 0.01))
-            ok[np.nonzero(active)[0]] = bm.last.success
+        if bm.last is not None:                              # None: every controller took the early exit this tick
+            ok[bm.last_rows] = bm.last.success
         q = q + u * p.dt                                     # mpc_action_server.py:98,135
         base_next = platform_state(motion, amplitude, phase, (tick + 1) * p.dt)
         ee = world_ee_pose(ctx.fk(up(q)).cpu().numpy(), base_next)

@@ -55,13 +55,12 @@ class HostScenarios:
 
 
 def world_to_base(v: np.ndarray, yaw: np.ndarray) -> np.ndarray:
-    """Batched ur_mpc.py:714-720."""
+    """Batched ur_mpc.py:714-720: the 3x3 rotation matrix times the vector, as a stacked matrix-vector
+    product (numpy runs the same BLAS routine per row as the reference's ``R @ v``: identical bits)."""
     c, s = np.cos(yaw), np.sin(yaw)
-    out = np.empty_like(v)
-    out[:, 0] = c * v[:, 0] + s * v[:, 1]
-    out[:, 1] = -s * v[:, 0] + c * v[:, 1]
-    out[:, 2] = v[:, 2]
-    return out
+    R = np.zeros((v.shape[0], 3, 3))
+    R[:, 0, 0], R[:, 0, 1], R[:, 1, 0], R[:, 1, 1], R[:, 2, 2] = c, s, -s, c, 1.0
+    return (R @ v[:, :, None])[:, :, 0]
 
 
 def dls_guess(Jc: np.ndarray, base: np.ndarray, ee_pos: np.ndarray) -> np.ndarray:
@@ -72,9 +71,10 @@ def dls_guess(Jc: np.ndarray, base: np.ndarray, ee_pos: np.ndarray) -> np.ndarra
     ta = world_to_base(-Om, Th[:, 2])
     twist = np.concatenate([tl, ta], axis=1)
     J = Jc.reshape(-1, 6, 6)
-    JJt = J @ np.transpose(J, (0, 2, 1)) + 0.01 * np.eye(6)
-    y = np.linalg.solve(JJt, twist[:, :, None])
-    return (np.transpose(J, (0, 2, 1)) @ y)[:, :, 0]
+    Jt = np.transpose(J, (0, 2, 1))
+    # the reference's operation order, (J^T inv(J J^T + 0.01 I)) twist, so that start points round as its do
+    pinv = Jt @ np.linalg.inv(J @ Jt + 0.01 * np.eye(6))
+    return (pinv @ twist[:, :, None])[:, :, 0]
 
 
 def platform_state(motion: str, amplitude: np.ndarray, phase: np.ndarray, t: float = 0.0) -> np.ndarray:

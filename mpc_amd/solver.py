@@ -226,8 +226,8 @@ class BatchedMPC:
     def __init__(self, ctx: MpcContext, solver=None, prep: str = "host"):
         """`solver`: anything with ``solve(ScenarioBatch, x0) -> BatchSolveResult`` on this context
         (default: the in-process BatchedSLSQP; pass a ``mpc_amd.pool.SolverPool`` to use more cores).
-        `prep`: where the per-tick inputs are assembled.  "host" solves the 6x6 DLS system with LAPACK
-        as the reference does (start points bit-compatible with it); "device" does everything in one
+        `prep`: where the per-tick inputs are assembled.  "host" forms the DLS start with numpy in
+        the reference's operation order, J^T inv(J J^T + 0.01 I) twist (start points bit-compatible with it); "device" does everything in one
         launch of ``mpc_prepare_tick`` (start points equal to rounding; for very large batches)."""
         if prep not in ("host", "device"):
             raise ValueError("prep must be 'host' or 'device'")
@@ -236,7 +236,8 @@ class BatchedMPC:
         self.solver = solver if solver is not None else BatchedSLSQP(ctx)
         self.previous_solution: Optional[np.ndarray] = None   # [N, n], NaN rows = no solution yet
         self.previous_control: Optional[np.ndarray] = None    # [N, 6], NaN rows = attribute absent
-        self.last: Optional[BatchSolveResult] = None
+        self.last: Optional[BatchSolveResult] = None     # the solve of the latest tick; None if that tick solved nothing
+        self.last_rows: np.ndarray = np.zeros(0, dtype=np.int64)   # controllers (rows) `last` refers to
         self._kin: Optional[BatchedKinematicPredictor] = None
 
     def compute_control(self, q: np.ndarray, ee_pose: np.ndarray, target: np.ndarray, base: np.ndarray) -> np.ndarray:
@@ -251,6 +252,7 @@ class BatchedMPC:
         out = np.zeros((N, 6))
         active = ~((np.linalg.norm(base[:, 6:9], axis=1) < 0.01) & (np.linalg.norm(base[:, 9:12], axis=1) < 0.01))
         idx = np.nonzero(active)[0]
+        self.last, self.last_rows = None, idx        # `last` belongs to this tick (None: every controller exited early)
         if len(idx) == 0:
             return out
         dev = ctx.device

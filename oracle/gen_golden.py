@@ -136,6 +136,91 @@ def save_solve(cases):
             control=np.stack([c["control"] for c in cs]), solution=np.stack([c["solution"] for c in cs]))
 
 
+def _solve_one_h20(args):
+    """One configs[2]-shaped controller (H=20) through two compute_control ticks of the real reference."""
+    motion, i, row = args
+    H = 20
+    ref = _ref_for(H)
+    q0, ee0, target, b = row
+    js = {"position": q0.copy(), "velocity": np.zeros(6)}
+    ee = {"position": ee0[:3].copy(), "orientation": ee0[3:].copy()}
+    tg = {"position": target[:3].copy(), "orientation": target[3:].copy()}
+    bs = {"position": b[0:3].copy(), "orientation": b[3:6].copy(), "linear_velocity": b[6:9].copy(),
+          "angular_velocity": b[9:12].copy()}
+    controls, sols = [], []
+    t0 = time.time()
+    for tick in range(2):
+        with contextlib.redirect_stdout(io.StringIO()):
+            u = ref.compute_control(js, ee, tg, bs)
+        controls.append(np.array(u))
+        sols.append(np.array(ref.previous_solution))
+    print(f"solve H=20 {motion} row {i}: u0={controls[0][:3]} ({time.time()-t0:.1f}s)", flush=True)
+    return dict(H=H, motion=motion, q0=q0, ee=ee0, target=target, base=b, control=np.stack(controls),
+                solution=np.stack(sols))
+
+
+def _closed_loop_h20(args):
+    """`ticks` ticks of the action server's loop (mpc_action_server.py:77-135) around the real reference
+    at H=20, the platform following simulate_platform_motion.py's sinusoid: joint trajectory + commands."""
+    from mpc_amd.scenarios import platform_state, world_ee_pose
+    from oracle.numpy_ref import ur20_fk
+
+    motion, q0, amplitude, phase, ticks = args
+    H = 20
+    mp = MpcParams.reference_yaml_defaults(horizon=H)
+    ref = _ref_for(H)
+    fk = lambda qq, b: world_ee_pose(np.concatenate(ur20_fk(qq))[None], b)[0]
+    q = q0.copy()
+    ee = fk(q, platform_state(motion, amplitude, phase, 0.0))
+    target = {"position": ee[:3].copy(), "orientation": ee[3:].copy()}     # mpc_action_server.py:77
+    qs, us = [q.copy()], []
+    t0 = time.time()
+    for t in range(ticks):
+        b = platform_state(motion, amplitude, phase, t * mp.dt)[0]
+        bs = {"position": b[0:3], "orientation": b[3:6], "linear_velocity": b[6:9], "angular_velocity": b[9:12]}
+        with contextlib.redirect_stdout(io.StringIO()):
+            u = ref.compute_control({"position": q, "velocity": np.zeros(6)},
+                                    {"position": ee[:3], "orientation": ee[3:]}, target, bs)
+        q = q + np.asarray(u) * mp.dt                                       # mpc_action_server.py:98,135
+        ee = fk(q, platform_state(motion, amplitude, phase, (t + 1) * mp.dt))
+        qs.append(q.copy()); us.append(np.array(u))
+    print(f"closed loop H=20 {motion}: {ticks} ticks ({time.time()-t0:.1f}s)", flush=True)
+    return dict(motion=motion, q0=q0, amplitude=amplitude, phase=phase, q=np.stack(qs), u=np.stack(us))
+
+
+def h20_cases(workers=4):
+    """BASELINE configs[2]'s workload pinned to the reference: the first rows of the very scenario list
+    bench.py's solves leg runs (angular, cfg_id 3, goal_jitter 0) plus linear ones, two ticks each, and one
+    4-tick closed-loop trajectory per motion type.  ~40 s per solve on one core -> run in a small pool."""
+    import multiprocessing as mpx
+
+    H = 20
+    mp = MpcParams.reference_yaml_defaults(horizon=H)
+    kin = OracleKinematics(COracle(ref_params_from(mp)))
+    jobs = []
+    for motion, n_s in (("angular", 4), ("linear", 3)):
+        hs = make_scenarios(mp, kin, 12, motion=motion, cfg_id=3, goal_jitter=0.0)
+        rows = [i for i in range(12) if hs.active[i]][:n_s]
+        jobs += [(motion, i, (hs.q0[i], hs.state0[i, 12:18], hs.target[i], hs.base[i])) for i in rows]
+    loops = []
+    for motion in ("angular", "linear"):
+        hs = make_scenarios(mp, kin, 2, motion=motion, cfg_id=7)
+        loops.append((motion, hs.q0[1], float(hs.amplitude[1]), float(hs.phase[1]), 4))
+    with mpx.get_context("spawn").Pool(workers) as pool:
+        loop_async = pool.map_async(_closed_loop_h20, loops)
+        cs = pool.map(_solve_one_h20, jobs)
+        ls = loop_async.get()
+    np.savez_compressed(
+        os.path.join(OUT, "solve_H20_cfg3.npz"), H=np.int64(H), motion=np.array([c["motion"] for c in cs]),
+        q0=np.stack([c["q0"] for c in cs]), ee=np.stack([c["ee"] for c in cs]),
+        target=np.stack([c["target"] for c in cs]), base=np.stack([c["base"] for c in cs]),
+        control=np.stack([c["control"] for c in cs]), solution=np.stack([c["solution"] for c in cs]))
+    np.savez_compressed(
+        os.path.join(OUT, "closed_loop_H20.npz"), H=np.int64(H), motion=np.array([c["motion"] for c in ls]),
+        q0=np.stack([c["q0"] for c in ls]), amplitude=np.array([c["amplitude"] for c in ls]),
+        phase=np.array([c["phase"] for c in ls]), q=np.stack([c["q"] for c in ls]), u=np.stack([c["u"] for c in ls]))
+
+
 def base_motion_cases():
     """predict_base_motion of the reference: dynamic model and 3 ticks of the stateful kinematic one."""
     rng = np.random.default_rng(77)
@@ -163,9 +248,13 @@ def main():
     if not ref_shim.reference_available():
         sys.exit("reference tree not present: fixtures can only be generated where /root/reference exists")
     os.makedirs(OUT, exist_ok=True)
+    if "--h20" in sys.argv:          # only the configs[2] solve fixtures (the others stay as committed)
+        h20_cases()
+        return
     base_motion_cases()
     save_eval(eval_cases())
     save_solve(solve_cases())
+    h20_cases()
 
 
 if __name__ == "__main__":
