@@ -21,13 +21,14 @@
 #ifndef MPC_AMD_H
 #define MPC_AMD_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
 extern "C" {
 #endif
 
-#define MPC_AMD_ABI_VERSION 6
+#define MPC_AMD_ABI_VERSION 7
 #define MPC_MAX_HORIZON 255
 
 typedef enum mpc_status {
@@ -206,10 +207,41 @@ int mpc_qp_solve(mpc_ctx *ctx, int count, const double *l, const double *g, cons
  * Per-problem state, `rows` rows each, owned by the caller and only touched by this call: L [(n+1)n/2 + 1],
  * R [m + 2n], V [n]; inputs per problem G [n], C [m], NZ [6H + 3H(H+1)] (what mpc_eval / mpc_eval_fd_nz returned at
  * the problem's current iterate).  Per request (position k in the list): flags, lo, hi, s_in [n] in;
- * s_out [n], r_out [m] (constraint multipliers), mode out.  Bit-identical to the host core. */
+ * s_out [n], r_out [m] (constraint multipliers), mode out.  Bit-identical to the host core.
+ * The indices must be distinct (two requests for one problem would race on its state).  A request whose index lies
+ * outside [0, rows) touches no state and gets mode -100. */
 int mpc_qp_step(mpc_ctx *ctx, int count, int rows, const int32_t *index, const int32_t *flags, const double *lo,
                 const double *hi, const double *s_in, double *L, const double *G, const double *C, const double *NZ, double *R,
                 double *V, double *s_out, double *r_out, int32_t *mode, void *stream);
+
+/* Whole SLSQP solves resident on the device: replaces scipy's driver loop around its compiled core
+ * (SLSQP:427-456, called from MPC:188-200) for sc->count problems at once, with nothing but an "unfinished" count
+ * crossing PCIe between the start point going in and the solutions coming out.  Per round and problem: one call of
+ * Kraft's SLSQP body (merit function, line search, convergence tests: the text of mpc_amd/csrc/slsqp_body.inc, the same
+ * file the host core of libmpc_slsqp.so is compiled from) as a one-thread-per-problem kernel, which sorts the
+ * unfinished problems into three device-side request lists; then f and c (mpc_eval), grad f and the structured dc/dx
+ * (mpc_eval_fd_nz) and the BFGS update + QP (mpc_qp_step) for the problems on each list, all reading the lists and
+ * their lengths from device memory.  Iterates, exit modes and iteration counts are those of the host drivers, bit for bit.
+ *   ws: caller-owned device workspace of mpc_solve_workspace_bytes(H, rows) bytes, 256-byte aligned, rows >= sc->count
+ *       (85 KB per row at H = 20); it holds every problem's state between the calls.
+ *   mpc_solve_begin:  x0 [N][n] is clipped into the box +-v_lim (SLSQP:268, MPC:420-430), the state of a first call
+ *       is set up (acc = ftol, maxiter: MPC:195-196) and f, c, grad f, dc/dx are evaluated at the start point
+ *       (SLSQP:419-425).  Also sizes the context's QP workspace, so that mpc_solve_rounds never allocates.
+ *   mpc_solve_rounds: enqueues `rounds` rounds.  `bound` >= the number of unfinished problems sizes the grids (pass
+ *       sc->count, or the count a previous call reported).  After the last round the number of problems that were
+ *       still unfinished in it is copied to *unfinished (device or pinned host memory, may be NULL) on the stream;
+ *       0 means every problem has stopped.  Rounds after that are harmless no-ops.  A problem whose linearisation
+ *       is inconsistent stops with status 104 (solve it again with the host driver, include/mpc_slsqp.h).
+ *   mpc_solve_result: x [N][n], fun [N], nit [N], status [N] (SLSQP's exit mode, 0 = converged) and, if non-NULL,
+ *       stats[4] = {mpc_eval requests, mpc_eval_fd_nz requests, QP steps, unfinished in the last round} (device).
+ * `sc` must be the same batch in all three calls; calls on one context / one workspace must not overlap. */
+size_t mpc_solve_workspace_bytes(int horizon, int rows);
+int mpc_solve_begin(mpc_ctx *ctx, const mpc_scenarios *sc, const double *x0, double acc, int maxiter, void *ws, int rows,
+                    size_t ws_bytes, void *stream);
+int mpc_solve_rounds(mpc_ctx *ctx, const mpc_scenarios *sc, void *ws, int rows, size_t ws_bytes, int rounds, int bound,
+                     int32_t *unfinished, void *stream);
+int mpc_solve_result(mpc_ctx *ctx, int count, void *ws, int rows, size_t ws_bytes, double *x, double *fun, int32_t *nit,
+                     int32_t *status, int32_t *stats, void *stream);
 
 /* Active-set gather for lock-step solves: scipy's driver evaluates a problem only when its SLSQP core
  * asks (mode 1 / -1, _slsqp_py.py:427-456), so each round of a batched solve touches a changing subset

@@ -23,6 +23,7 @@ _UNITS = {
     "kernels_aux.hip": _STRICT,
     "kernels_prefix.hip": _STRICT,  # fused multiply-adds are written out with fma() there
     "kernels_qp.hip": _STRICT,      # bit-identical to the host SLSQP core
+    "kernels_slsqp.hip": _STRICT,   # Kraft's body on the device: the host core's text, one rounding per operation
 }
 _COMMON = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function",
            "-I" + os.path.join(_ROOT, "include"), "-I" + CSRC]
@@ -44,7 +45,7 @@ def _stale(target: str, deps) -> bool:
 
 def build(force: bool = False, verbose: bool = False) -> str:
     hipcc = _hipcc()
-    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp")]
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hpp", ".inc", ".h"))]
     headers.append(os.path.join(_ROOT, "include", "mpc_amd.h"))
     objdir = os.path.join(_HERE, "build")
     os.makedirs(objdir, exist_ok=True)
@@ -73,7 +74,8 @@ def build_slsqp(force: bool = False, verbose: bool = False) -> str:
     if gcc is None:
         raise RuntimeError("gcc not found: libmpc_slsqp.so cannot be built")
     srcs = [os.path.join(CSRC, u) for u in _SLSQP_UNITS]
-    deps = srcs + [os.path.join(CSRC, "slsqp_core.h"), os.path.join(_ROOT, "include", "mpc_slsqp.h")]
+    deps = srcs + [os.path.join(CSRC, "slsqp_core.h"), os.path.join(CSRC, "slsqp_body.inc"),
+                   os.path.join(_ROOT, "include", "mpc_slsqp.h")]
     spmd = [os.path.join(CSRC, "lsq_spmd_host.cpp"), os.path.join(CSRC, "lsq_spmd.hpp")]
     if force or _stale(SLSQP_LIB_PATH, deps + spmd):
         objdir = os.path.join(_HERE, "build")

@@ -38,6 +38,9 @@ struct PrefixArgs {
     int cstride;      // doubles per scenario in `compact`
     int S;            // scenarios per workgroup
     int items;        // phase-2 lanes per scenario = 6 * ceil(H/2)
+    // ROWS form (device-resident solves): evaluate rows list[0 .. *count_dev) of every array in place
+    const int32_t *list;
+    const int32_t *count_dev;
 };
 
 // How the forward-difference work is organised:
@@ -239,7 +242,7 @@ __device__ __forceinline__ double pick6(const double (&a)[6], int j)
     return v;
 }
 
-template <int MODE, bool SAME_DT, int MAXT>
+template <int MODE, bool SAME_DT, int MAXT, bool ROWS = false>
 __global__ __launch_bounds__(MAXT) void prefix_kernel(const mpc_params P, const PrefixArgs A)
 {
     extern __shared__ __align__(16) double lds[];
@@ -250,24 +253,32 @@ __global__ __launch_bounds__(MAXT) void prefix_kernel(const mpc_params P, const 
     double *dec = lds;  // [H], shared by the scenarios of the workgroup
     double *scen = lds + ((H + 1) & ~1);
     const int s0 = blockIdx.x * A.S;
-    const int ns = min(A.S, A.sc.count - s0);
+    const int ns = min(A.S, (ROWS ? *A.count_dev : A.sc.count) - s0);
+    if (ROWS && ns <= 0) return;                 // grid sized by an upper bound of the list length
+    // row of local scenario ls in the caller's arrays: consecutive, or taken from the request list
+    auto row = [&](int ls) -> size_t { return ROWS ? (size_t)A.list[s0 + ls] : (size_t)(s0 + ls); };
 
     // ---- stage the scenarios' inputs: rows of consecutive scenarios are contiguous in HBM ------
     for (int i = tid; i < H; i += bs) dec[i] = A.decay[i];
     for (int f = tid; f < ns * n; f += bs) {
         const int ls = f / n;
-        scen[ls * Y.total + Y.xs + (f - ls * n)] = A.x[(size_t)s0 * n + f];
+        scen[ls * Y.total + Y.xs + (f - ls * n)] = A.x[ROWS ? row(ls) * n + (f - ls * n) : (size_t)s0 * n + f];
     }
     for (int f = tid; f < ns * 12 * H; f += bs) {
         const int ls = f / (12 * H);
-        scen[ls * Y.total + Y.bt + (f - ls * 12 * H)] = A.sc.base_traj[(size_t)s0 * 12 * H + f];
+        scen[ls * Y.total + Y.bt + (f - ls * 12 * H)] =
+            A.sc.base_traj[ROWS ? row(ls) * 12 * H + (f - ls * 12 * H) : (size_t)s0 * 12 * H + f];
     }
-    for (int f = tid; f < ns * 18; f += bs) scen[(f / 18) * Y.total + Y.st0 + f % 18] = A.sc.state0[(size_t)s0 * 18 + f];
-    for (int f = tid; f < ns * 6; f += bs) scen[(f / 6) * Y.total + Y.tgt + f % 6] = A.sc.target[(size_t)s0 * 6 + f];
-    for (int f = tid; f < ns * 36; f += bs) scen[(f / 36) * Y.total + Y.Jc + f % 36] = A.sc.Jc[(size_t)s0 * 36 + f];
+    for (int f = tid; f < ns * 18; f += bs)
+        scen[(f / 18) * Y.total + Y.st0 + f % 18] = A.sc.state0[ROWS ? row(f / 18) * 18 + f % 18 : (size_t)s0 * 18 + f];
+    for (int f = tid; f < ns * 6; f += bs)
+        scen[(f / 6) * Y.total + Y.tgt + f % 6] = A.sc.target[ROWS ? row(f / 6) * 6 + f % 6 : (size_t)s0 * 6 + f];
+    for (int f = tid; f < ns * 36; f += bs)
+        scen[(f / 36) * Y.total + Y.Jc + f % 36] = A.sc.Jc[ROWS ? row(f / 36) * 36 + f % 36 : (size_t)s0 * 36 + f];
     const bool any_prev = A.sc.u_prev != nullptr && A.sc.has_prev != nullptr;
     for (int f = tid; f < ns * 6; f += bs)
-        scen[(f / 6) * Y.total + Y.up + f % 6] = any_prev ? A.sc.u_prev[(size_t)s0 * 6 + f] : 0.0;
+        scen[(f / 6) * Y.total + Y.up + f % 6] =
+            any_prev ? A.sc.u_prev[ROWS ? row(f / 6) * 6 + f % 6 : (size_t)s0 * 6 + f] : 0.0;
     __syncthreads();
     for (int f = tid; f < ns * H; f += bs) {
         const int ls = f / H, k = f - ls * H;
@@ -283,7 +294,7 @@ __global__ __launch_bounds__(MAXT) void prefix_kernel(const mpc_params P, const 
     const int ls1 = act1 ? tid / L : 0;
     const int k1 = act1 ? tid - ls1 * L : 0;
     double *S1 = scen + ls1 * Y.total;
-    const bool has_prev1 = any_prev && A.sc.has_prev[s0 + ls1] != 0;
+    const bool has_prev1 = any_prev && A.sc.has_prev[row(ls1)] != 0;
     double u1[6], w1[6], vc1[6];
     if (act1) {
         const int k = k1;
@@ -323,7 +334,7 @@ __global__ __launch_bounds__(MAXT) void prefix_kernel(const mpc_params P, const 
             for (int c = 0; c < 6; ++c) vc1[c] = w1[c];    // terminal: J(q_H) dq_H (MPC:344-345)
         }
         if (A.con != nullptr) {                            // MPC:394-409
-            double2 *dst = reinterpret_cast<double2 *>(A.con + (size_t)(s0 + ls1) * m + 12 * k);
+            double2 *dst = reinterpret_cast<double2 *>(A.con + row(ls1) * m + 12 * k);
             double c0[12];
 #pragma unroll
             for (int j = 0; j < 6; ++j) {
@@ -362,7 +373,7 @@ __global__ __launch_bounds__(MAXT) void prefix_kernel(const mpc_params P, const 
         for (int jj = 0; jj < k; ++jj) tot = tot + S1[Y.lb + jj];  // MPC:683, left to right
         if (k == H) {
             const double f0 = tot + S1[Y.lb + H];                   // MPC:690
-            A.cost[s0 + ls1] = f0;
+            A.cost[row(ls1)] = f0;
             S1[Y.Cp + H + 1] = f0;
         }
         // Cp lives apart from lb (which aliases jpos): every lane has read lb before any writes jpos
@@ -377,7 +388,7 @@ __global__ __launch_bounds__(MAXT) void prefix_kernel(const mpc_params P, const 
     const int it = act2 ? tid - ls2 * A.items : 0;
     const int pi = it / 6, a = it - 6 * pi;
     double *S2 = scen + ls2 * Y.total;
-    const bool has_prev2 = any_prev && A.sc.has_prev[s0 + ls2] != 0;
+    const bool has_prev2 = any_prev && A.sc.has_prev[row(ls2)] != 0;
     const int j_first = pi, j_second = H - 1 - pi;
     const int npert = (j_second > j_first) ? 2 : 1;
     const double lim = pick6(P.v_lim, a), qlo = pick6(P.q_lo, a), qhi = pick6(P.q_hi, a);
@@ -458,13 +469,13 @@ __global__ __launch_bounds__(MAXT) void prefix_kernel(const mpc_params P, const 
                 S2[Y.jpos + 6 * (tri_j + k + 1) + a] = jp;
                 if (k == j) S2[Y.jvel + var] = jv;
             } else if (A.jac != nullptr) {
-                double *cz = A.compact + (size_t)(s0 + ls2) * A.cstride;
+                double *cz = A.compact + row(ls2) * A.cstride;
                 cz[6 * H + 6 * (tri_j + k + 1) + a] = jp;
                 if (k == j) cz[var] = jv;
             }
             k = k + 1;
         } else {
-            if (A.grad != nullptr) A.grad[(size_t)(s0 + ls2) * n + var] = quot(acc - f0, dx, rdx);  // NUMDIFF:619
+            if (A.grad != nullptr) A.grad[row(ls2) * n + var] = quot(acc - f0, dx, rdx);  // NUMDIFF:619
             pert = pert + 1;
             if (pert < npert) need_init = true; else active = false;
         }
@@ -614,19 +625,19 @@ bool compact_ok(const mpc_params &P)
     return g.threads <= 512 && g.lds <= (size_t)kMaxLdsLarge;
 }
 
-template <int MODE, int MAXT>
+template <int MODE, int MAXT, bool ROWS = false>
 hipError_t launch_mode(const mpc_params &P, const PrefixArgs &A, const Geometry &g, unsigned grid, hipStream_t stream)
 {
     const bool same_dt = P.dt_cost == P.dt_con;
     if (g.lds > 48 * 1024) {  // above the default dynamic-LDS limit
-        hipError_t e = same_dt ? hipFuncSetAttribute(reinterpret_cast<const void *>(prefix_kernel<MODE, true, MAXT>),
+        hipError_t e = same_dt ? hipFuncSetAttribute(reinterpret_cast<const void *>(prefix_kernel<MODE, true, MAXT, ROWS>),
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds)
-                               : hipFuncSetAttribute(reinterpret_cast<const void *>(prefix_kernel<MODE, false, MAXT>),
+                               : hipFuncSetAttribute(reinterpret_cast<const void *>(prefix_kernel<MODE, false, MAXT, ROWS>),
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds);
         if (e != hipSuccess) return e;
     }
-    if (same_dt) hipLaunchKernelGGL((prefix_kernel<MODE, true, MAXT>), dim3(grid), dim3(g.threads), g.lds, stream, P, A);
-    else hipLaunchKernelGGL((prefix_kernel<MODE, false, MAXT>), dim3(grid), dim3(g.threads), g.lds, stream, P, A);
+    if (same_dt) hipLaunchKernelGGL((prefix_kernel<MODE, true, MAXT, ROWS>), dim3(grid), dim3(g.threads), g.lds, stream, P, A);
+    else hipLaunchKernelGGL((prefix_kernel<MODE, false, MAXT, ROWS>), dim3(grid), dim3(g.threads), g.lds, stream, P, A);
     return hipGetLastError();
 }
 
@@ -661,9 +672,31 @@ hipError_t launch_prefix_nz(const mpc_params &P, const double *decay, const mpc_
     A.jac = nz;      // kCompact only tests it against NULL ("the quotients are wanted")
     A.compact = nz; A.cstride = (int)jacobian_nz_count(P.horizon);
     A.S = g.S; A.items = g.items;
+    A.list = nullptr; A.count_dev = nullptr;
     const unsigned grid = (unsigned)((sc.count + g.S - 1) / g.S);
     return g.threads <= 128 ? launch_mode<kCompact, 128>(P, A, g, grid, stream)
                             : launch_mode<kCompact, 512>(P, A, g, grid, stream);
+}
+
+hipError_t launch_prefix_rows(const mpc_params &P, const double *decay, const mpc_scenarios &sc, const double *x, double *cost,
+                              double *grad, double *con, double *nz, const RowList &rows, hipStream_t stream)
+{
+    if (!prefix_nz_supported(P) || rows.list == nullptr || rows.count == nullptr) return hipErrorNotSupported;
+    if (rows.bound <= 0) return hipSuccess;
+    const bool fd = grad != nullptr || nz != nullptr;
+    const int mode = fd ? kCompact : kEval;
+    const Geometry g = geometry(P, mode);
+    PrefixArgs A;
+    A.decay = decay; A.sc = sc; A.x = x; A.cost = cost; A.grad = grad; A.con = con;
+    A.jac = nz; A.compact = nz; A.cstride = (int)jacobian_nz_count(P.horizon);
+    A.S = g.S; A.items = g.items;
+    A.list = rows.list; A.count_dev = rows.count;
+    const unsigned grid = (unsigned)((rows.bound + g.S - 1) / g.S);
+    if (!fd)
+        return g.threads <= 128 ? launch_mode<kEval, 128, true>(P, A, g, grid, stream)
+                                : launch_mode<kEval, 512, true>(P, A, g, grid, stream);
+    return g.threads <= 128 ? launch_mode<kCompact, 128, true>(P, A, g, grid, stream)
+                            : launch_mode<kCompact, 512, true>(P, A, g, grid, stream);
 }
 
 hipError_t launch_expand(const mpc_params &P, int count, const double *nz, double *jac, hipStream_t stream)
@@ -690,6 +723,7 @@ hipError_t launch_prefix(const mpc_params &P, const double *decay, const mpc_sce
     A.decay = decay; A.sc = sc; A.x = x; A.cost = cost; A.grad = grad; A.con = con; A.jac = jac;
     A.compact = nullptr; A.cstride = 0;
     A.S = g.S; A.items = g.items;
+    A.list = nullptr; A.count_dev = nullptr;
     if (mode != kCompact) {
         const unsigned grid = (unsigned)((sc.count + g.S - 1) / g.S);
         if (mode == kEval) return fused ? launch_mode<kEval, 128>(P, A, g, grid, stream) : launch_mode<kEval, 512>(P, A, g, grid, stream);

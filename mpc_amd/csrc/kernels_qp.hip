@@ -73,23 +73,34 @@ qp_kernel(int H, int count, const double *__restrict__ l, const double *__restri
 // Lagrangian gradient v = g - (dc/dx)^T r for the next update.  State rows are addressed by problem, the
 // request's own arrays by position in the list.  The factor is staged in the team's triangle (W.E), updated
 // there, written back, and then turned in place into the QP's e.
-template <bool kLds>
+// kRows (device-resident solves, kernels_slsqp.hip): the request list and its length come from device memory
+// (`count` is then only an upper bound), and the request's box, last step, new step and mode are the problem's own
+// rows (lo, hi, s_in = s_out, mode indexed by problem instead of by position in the list; r_out unused: the
+// multipliers stay in R).
+template <bool kLds, bool kRows>
 __global__ void __launch_bounds__(mpck::kQpThreads, MPC_QP_WAVES)
-qp_step_kernel(int H, int count, const int32_t *__restrict__ index, const int32_t *__restrict__ flags,
-               const double *__restrict__ lo, const double *__restrict__ hi, const double *__restrict__ s_in, double *L,
-               const double *__restrict__ G, const double *__restrict__ C, const double *__restrict__ NZ, double *R, double *V,
-               double *__restrict__ s_out, double *__restrict__ r_out, int32_t *__restrict__ mode, double *work, int *iwork,
+qp_step_kernel(int H, int count, int rows, const int32_t *__restrict__ index, const int32_t *__restrict__ count_dev,
+               const int32_t *__restrict__ flags, const double *__restrict__ lo, const double *__restrict__ hi, const double *s_in,
+               double *L, const double *__restrict__ G, const double *__restrict__ C, const double *__restrict__ NZ, double *R,
+               double *V, double *s_out, double *__restrict__ r_out, int32_t *__restrict__ mode, double *work, int *iwork,
                size_t wd, size_t wi)
 {
     const int n = 6 * H, m = 12 * (H + 1), mg = m + 2 * n, nzc = 6 * H + 3 * H * (H + 1);
     const int ldl = (n + 1) * n / 2 + 1;
     const lsqspmd::Work W = team_work<kLds>(work, iwork, wd, wi, n, m);
     const HipTeam T;
+    if (kRows) count = *count_dev;
     for (int k = (int)blockIdx.x; k < count; k += (int)gridDim.x) {
-        const size_t p = (size_t)index[k];
+        const int pi = index[k];
+        const size_t q = kRows ? (size_t)pi : (size_t)k;        // row of the per-request arrays
+        if (pi < 0 || pi >= rows) {                              // never address state outside the caller's rows
+            if (threadIdx.x == 0 && !kRows) mode[q] = MPC_QP_MODE_BAD_INDEX;
+            continue;
+        }
+        const size_t p = (size_t)pi;
         double *l = L + p * ldl, *r = R + p * mg, *v = V + p * n;
         const double *g = G + p * n, *c = C + p * m, *nz = NZ + p * nzc;
-        const int fl = flags[k];
+        const int fl = flags[q];
         if (fl & 1) {                                            // the factor of the identity
             PAR_FOR(T, e, 0, ldl - 1) W.E[e] = 0.0;
             T.sync();
@@ -100,7 +111,7 @@ qp_step_kernel(int H, int count, const int32_t *__restrict__ index, const int32_
         if (fl & 2) {
             PAR_FOR(T, i, 0, n) {
                 W.bb[i] = v[i];
-                W.zz[i] = s_in[(size_t)k * n + i];
+                W.zz[i] = s_in[q * n + i];
             }
             T.sync();
             lsqspmd::bfgs_update(T, W, H, W.E, g, nz, r, W.bb, W.zz, W.xs);
@@ -108,15 +119,15 @@ qp_step_kernel(int H, int count, const int32_t *__restrict__ index, const int32_
         T.sync();
         if (fl & 3) PAR_FOR(T, e, 0, ldl - 1) l[e] = W.E[e];
         T.sync();
-        const int md = lsqspmd::lsq(T, W, H, g, c, nz, lo + (size_t)k * n, hi + (size_t)k * n, s_out + (size_t)k * n, r);
+        const int md = lsqspmd::lsq(T, W, H, g, c, nz, lo + q * n, hi + q * n, s_out + q * n, r);
         T.sync();
         if (md == 1) {
             PAR_FOR(T, i, 0, n) {
                 v[i] = g[i] - lsqspmd::jac_column_dot(H, nz, r, i);
             }
-            PAR_FOR(T, i, 0, m) r_out[(size_t)k * m + i] = r[i];
+            if (!kRows) PAR_FOR(T, i, 0, m) r_out[q * m + i] = r[i];
         }
-        if (threadIdx.x == 0) mode[k] = md;
+        if (threadIdx.x == 0) mode[q] = md;
         __syncthreads();
     }
 }
@@ -141,23 +152,47 @@ int qp_teams_per_cu(int H)
     return t < 1 ? 1 : (t > 4 ? 4 : t);
 }
 
-hipError_t launch_qp_step(int H, int count, int teams, const int32_t *index, const int32_t *flags, const double *lo,
+namespace {
+template <bool kRows>
+hipError_t launch_qp_step_any(int H, int count, int teams, int rows, const int32_t *index, const int32_t *count_dev,
+                              const int32_t *flags, const double *lo, const double *hi, const double *s_in, double *L, const double *G,
+                              const double *C, const double *NZ, double *R, double *V, double *s_out, double *r_out, int32_t *mode,
+                              double *work, int *iwork, hipStream_t stream)
+{
+    const size_t lds = lds_bytes(H);
+    if (lds) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(qp_step_kernel<true, kRows>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((qp_step_kernel<true, kRows>), dim3((unsigned)teams), dim3(kQpThreads), lds, stream, H, count, rows, index,
+                           count_dev, flags, lo, hi, s_in, L, G, C, NZ, R, V, s_out, r_out, mode, work, iwork, qp_work_doubles(H),
+                           qp_work_ints(H));
+    } else {
+        hipLaunchKernelGGL((qp_step_kernel<false, kRows>), dim3((unsigned)teams), dim3(kQpThreads), 0, stream, H, count, rows, index,
+                           count_dev, flags, lo, hi, s_in, L, G, C, NZ, R, V, s_out, r_out, mode, work, iwork, qp_work_doubles(H),
+                           qp_work_ints(H));
+    }
+    return hipGetLastError();
+}
+}  // namespace
+
+hipError_t launch_qp_step(int H, int count, int teams, int rows, const int32_t *index, const int32_t *flags, const double *lo,
                           const double *hi, const double *s_in, double *L, const double *G, const double *C, const double *NZ,
                           double *R, double *V, double *s_out, double *r_out, int32_t *mode, double *work, int *iwork,
                           hipStream_t stream)
 {
-    const size_t lds = lds_bytes(H);
-    if (lds) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(qp_step_kernel<true>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(qp_step_kernel<true>, dim3((unsigned)teams), dim3(kQpThreads), lds, stream, H, count, index, flags, lo,
-                           hi, s_in, L, G, C, NZ, R, V, s_out, r_out, mode, work, iwork, qp_work_doubles(H), qp_work_ints(H));
-    } else {
-        hipLaunchKernelGGL(qp_step_kernel<false>, dim3((unsigned)teams), dim3(kQpThreads), 0, stream, H, count, index, flags, lo,
-                           hi, s_in, L, G, C, NZ, R, V, s_out, r_out, mode, work, iwork, qp_work_doubles(H), qp_work_ints(H));
-    }
-    return hipGetLastError();
+    return launch_qp_step_any<false>(H, count, teams, rows, index, nullptr, flags, lo, hi, s_in, L, G, C, NZ, R, V, s_out, r_out, mode,
+                                     work, iwork, stream);
+}
+
+hipError_t launch_qp_step_rows(int H, int teams, int rows, const RowList &list, const int32_t *flags, const double *lo,
+                               const double *hi, double *S, double *L, const double *G, const double *C, const double *NZ,
+                               double *R, double *V, int32_t *mode, double *work, int *iwork, hipStream_t stream)
+{
+    if (list.bound <= 0) return hipSuccess;
+    const int t = teams < list.bound ? teams : list.bound;
+    return launch_qp_step_any<true>(H, list.bound, t, rows, list.list, list.count, flags, lo, hi, S, L, G, C, NZ, R, V, S, nullptr,
+                                    mode, work, iwork, stream);
 }
 
 size_t qp_work_doubles(int H) { return lsqspmd::work_doubles(6 * H, 12 * (H + 1), kQpThreads); }

@@ -446,8 +446,101 @@ int mpc_qp_step(mpc_ctx *ctx, int count, int rows, const int32_t *index, const i
     rc = qp_workspace(ctx);
     if (rc) return rc;
     const int teams = count < ctx->qp_teams ? count : ctx->qp_teams;
-    MPC_HIP(ctx, mpck::launch_qp_step(ctx->horizon, count, teams, index, flags, lo, hi, s_in, L, G, C, NZ, R, V, s_out, r_out,
+    MPC_HIP(ctx, mpck::launch_qp_step(ctx->horizon, count, teams, rows, index, flags, lo, hi, s_in, L, G, C, NZ, R, V, s_out, r_out,
                                       mode, ctx->d_qp_work, ctx->d_qp_iwork, static_cast<hipStream_t>(stream)));
+    return MPC_OK;
+}
+
+size_t mpc_solve_workspace_bytes(int horizon, int rows)
+{
+    if (horizon <= 0 || horizon > MPC_MAX_HORIZON || rows <= 0) return 0;
+    return mpck::solve_workspace_bytes(horizon, rows);
+}
+
+namespace {
+
+int check_solve(mpc_ctx *ctx, int count, const void *ws, int rows, size_t ws_bytes)
+{
+    int rc = check_ready(ctx);
+    if (rc) return rc;
+    if (resolve_algo(ctx) != MPC_ALGO_PREFIX || !mpck::prefix_nz_supported(ctx->params))
+        return fail(ctx, MPC_ERR_UNSUPPORTED, "device-resident solves need MPC_ALGO_PREFIX (UR twist pattern, H <= 170)");
+    if (!ws || rows <= 0 || count < 0 || count > rows)
+        return fail(ctx, MPC_ERR_INVALID_ARG, "workspace is NULL, or count %d outside [0, rows = %d]", count, rows);
+    if ((reinterpret_cast<uintptr_t>(ws) & 255u) != 0) return fail(ctx, MPC_ERR_INVALID_ARG, "workspace must be 256-byte aligned");
+    const size_t need = mpck::solve_workspace_bytes(ctx->horizon, rows);
+    if (ws_bytes < need)
+        return fail(ctx, MPC_ERR_INVALID_ARG, "workspace of %zu bytes, %zu needed for %d rows", ws_bytes, need, rows);
+    return MPC_OK;
+}
+
+}  // namespace
+
+int mpc_solve_begin(mpc_ctx *ctx, const mpc_scenarios *sc, const double *x0, double acc, int maxiter, void *ws, int rows,
+                    size_t ws_bytes, void *stream)
+{
+    if (!sc) return fail(ctx, MPC_ERR_INVALID_ARG, "scenarios is NULL");
+    int rc = check_solve(ctx, sc->count, ws, rows, ws_bytes);
+    if (rc) return rc;
+    rc = check_scenarios(ctx, sc, x0);
+    if (rc) return rc;
+    if (maxiter < 1 || !(acc == acc)) return fail(ctx, MPC_ERR_INVALID_ARG, "maxiter must be positive and acc a number");
+    if (sc->count == 0) return MPC_OK;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    MPC_HIP(ctx, hipSetDevice(ctx->device));
+    rc = qp_workspace(ctx);                    // allocated here, so that mpc_solve_rounds never allocates
+    if (rc) return rc;
+    const mpck::SolveWorkspace W = mpck::carve_solve_workspace(ws, ctx->horizon, rows);
+    MPC_HIP(ctx, mpck::launch_solve_begin(ctx->params, W, sc->count, x0, acc, maxiter, st));
+    // mode 0 on entry: f, c, grad f and dc/dx at the (clipped) start point for everyone (SLSQP:419-425)
+    MPC_HIP(ctx, mpck::launch_prefix_nz(ctx->params, ctx->d_decay, *sc, W.XE, W.F, W.G, W.C, W.NZ, st));
+    return MPC_OK;
+}
+
+int mpc_solve_rounds(mpc_ctx *ctx, const mpc_scenarios *sc, void *ws, int rows, size_t ws_bytes, int rounds, int bound,
+                     int32_t *unfinished, void *stream)
+{
+    if (!sc) return fail(ctx, MPC_ERR_INVALID_ARG, "scenarios is NULL");
+    int rc = check_solve(ctx, sc->count, ws, rows, ws_bytes);
+    if (rc) return rc;
+    if (sc->count > 0 && (!sc->state0 || !sc->target || !sc->base_traj || !sc->Jc))
+        return fail(ctx, MPC_ERR_INVALID_ARG, "state0/target/base_traj/Jc must be non-NULL");
+    if (rounds < 0 || bound < 0) return fail(ctx, MPC_ERR_INVALID_ARG, "rounds and bound must not be negative");
+    if (sc->count == 0 || rounds == 0) return MPC_OK;
+    if (!ctx->d_qp_work) return fail(ctx, MPC_ERR_INVALID_ARG, "mpc_solve_begin has not run on this context");
+    if (bound > sc->count) bound = sc->count;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    MPC_HIP(ctx, hipSetDevice(ctx->device));
+    const mpck::SolveWorkspace W = mpck::carve_solve_workspace(ws, ctx->horizon, rows);
+    mpck::RowList lf, lg, lq;
+    lf.list = W.LIST_F; lf.count = W.counters + 0; lf.bound = bound;
+    lg.list = W.LIST_G; lg.count = W.counters + 1; lg.bound = bound;
+    lq.list = W.LIST_Q; lq.count = W.counters + 2; lq.bound = bound;
+    for (int r = 0; r < rounds; ++r) {
+        MPC_HIP(ctx, mpck::launch_solve_body(ctx->horizon, W, sc->count, st));
+        if (bound == 0) continue;
+        // f and c where the line search asked for them (SLSQP:434-436)
+        MPC_HIP(ctx, mpck::launch_prefix_rows(ctx->params, ctx->d_decay, *sc, W.XE, W.F, nullptr, W.C, nullptr, lf, st));
+        // grad f and dc/dx at the accepted point (SLSQP:438-440); f and c there are already in place
+        MPC_HIP(ctx, mpck::launch_prefix_rows(ctx->params, ctx->d_decay, *sc, W.XE, W.F, W.G, nullptr, W.NZ, lg, st));
+        // BFGS update + QP of the problems that start a major iteration
+        MPC_HIP(ctx, mpck::launch_qp_step_rows(ctx->horizon, ctx->qp_teams, rows, lq, W.QPFLAGS, W.LO, W.HI, W.S, W.L, W.G, W.C, W.NZ,
+                                               W.RM, W.V, W.QPMODE, ctx->d_qp_work, ctx->d_qp_iwork, st));
+    }
+    if (unfinished) MPC_HIP(ctx, hipMemcpyAsync(unfinished, W.counters + 3, sizeof(int32_t), hipMemcpyDefault, st));
+    return MPC_OK;
+}
+
+int mpc_solve_result(mpc_ctx *ctx, int count, void *ws, int rows, size_t ws_bytes, double *x, double *fun, int32_t *nit,
+                     int32_t *status, int32_t *stats, void *stream)
+{
+    int rc = check_solve(ctx, count, ws, rows, ws_bytes);
+    if (rc) return rc;
+    if (count == 0) return MPC_OK;
+    if (!x || !fun || !nit || !status) return fail(ctx, MPC_ERR_INVALID_ARG, "x/fun/nit/status must be non-NULL");
+    MPC_HIP(ctx, hipSetDevice(ctx->device));
+    const mpck::SolveWorkspace W = mpck::carve_solve_workspace(ws, ctx->horizon, rows);
+    MPC_HIP(ctx, mpck::launch_solve_result(ctx->horizon, W, count, x, fun, nit, status, stats, static_cast<hipStream_t>(stream)));
     return MPC_OK;
 }
 

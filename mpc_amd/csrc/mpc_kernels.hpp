@@ -5,6 +5,8 @@
 
 #include "mpc_amd.h"
 
+struct slsqp_state;
+
 namespace mpck {
 
 // MPC_ALGO_ROLLOUT: one workgroup per (scenario, perturbation group), one lane per horizon step.
@@ -66,10 +68,44 @@ hipError_t launch_qp(int H, int count, int teams, const double *l, const double 
                      const double *lo, const double *hi, double *s, double *y, int32_t *mode, double *work, int *iwork,
                      hipStream_t stream);
 
-hipError_t launch_qp_step(int H, int count, int teams, const int32_t *index, const int32_t *flags, const double *lo,
+#define MPC_QP_MODE_BAD_INDEX (-100)   // mpc_qp_step: the request's problem index lies outside [0, rows)
+hipError_t launch_qp_step(int H, int count, int teams, int rows, const int32_t *index, const int32_t *flags, const double *lo,
                           const double *hi, const double *s_in, double *L, const double *G, const double *C, const double *NZ,
                           double *R, double *V, double *s_out, double *r_out, int32_t *mode, double *work, int *iwork,
                           hipStream_t stream);
+
+// ---- whole SLSQP solves resident on the device (kernels_slsqp.hip; mpc_solve_* in include/mpc_amd.h) ----------
+// The caller's workspace carved into per-problem rows (`rows` of them): iterate, evaluation point, line-search
+// origin, step, box, penalty multipliers, QP multipliers, f, c, grad f, structured dc/dx, LDL' factor, Lagrangian
+// gradient, the body's saved scalars, request lists and counters.
+struct SolveWorkspace {
+    int rows;
+    size_t bytes;
+    double *lb, *ub;
+    double *X, *XE, *X0, *S, *LO, *HI, *MU, *RM, *F, *C, *G, *NZ, *L, *V, *ACC;
+    ::slsqp_state *ST;
+    int32_t *MODE, *ITER, *QPMODE, *QPFLAGS, *DONE, *LIST_F, *LIST_G, *LIST_Q, *counters;
+};
+SolveWorkspace carve_solve_workspace(void *base, int H, int rows);
+size_t solve_workspace_bytes(int H, int rows);
+hipError_t launch_solve_begin(const mpc_params &P, const SolveWorkspace &W, int count, const double *x0, double acc, int maxiter,
+                              hipStream_t stream);
+hipError_t launch_solve_body(int H, const SolveWorkspace &W, int count, hipStream_t stream);
+hipError_t launch_solve_result(int H, const SolveWorkspace &W, int count, double *x, double *fun, int32_t *nit, int32_t *status,
+                               int32_t *stats, hipStream_t stream);
+hipError_t launch_copy_i32(const int32_t *src, int32_t *dst, hipStream_t stream);
+// One request list of a device-resident solve: evaluate rows list[0 .. *count) of the per-problem arrays in place
+// (x from XE, outputs to the problem's own rows).  `bound` >= *count sizes the grid; surplus workgroups exit.
+struct RowList {
+    const int32_t *list = nullptr;    // device, row numbers
+    const int32_t *count = nullptr;   // device, how many
+    int bound = 0;
+};
+hipError_t launch_prefix_rows(const mpc_params &P, const double *decay, const mpc_scenarios &sc, const double *x, double *cost,
+                              double *grad, double *con, double *nz, const RowList &rows, hipStream_t stream);
+hipError_t launch_qp_step_rows(int H, int teams, int rows, const RowList &list, const int32_t *flags, const double *lo,
+                               const double *hi, double *S, double *L, const double *G, const double *C, const double *NZ,
+                               double *R, double *V, int32_t *mode, double *work, int *iwork, hipStream_t stream);
 
 // dst row i = src row index[i] for every scenario array (NaN rows for an index outside [0, src.count))
 hipError_t launch_gather_scenarios(int H, const mpc_scenarios &src, const int32_t *index, int count,

@@ -634,158 +634,9 @@ void mpc_slsqp_bfgs_builtin(int m, int n, int la, double *l, double *g, double *
 void mpc_slsqpb(int m, int meq, int la, int n, double *x, double *xl, double *xu, double f, double *c, double *g, double *a,
                    double *acc, int *iter, int *mode, double *r, double *l, double *x0, double *mu, double *s, double *u,
                    double *v, double *w, int *iw, slsqp_state *S)
-{
-#define A(i, j) a[((i) - 1) + ((j) - 1) * la]
-    const double alfmin = 0.1;
-    int i, j, badlin = 0;
-    double alpha = S->alpha, f0 = S->f0, gs = S->gs, h1 = S->h1, h2 = S->h2, h3 = S->h3, h4 = S->h4, t = S->t, t0 = S->t0,
-           tol = S->tol;
-    int iexact = S->iexact, incons = S->incons, ireset = S->ireset, itermx = S->itermx, line = S->line, n1 = S->n1,
-        n2 = S->n2, n3 = S->n3;
-    if (*mode == MPC_SLSQP_MODE_QP) goto L135;
-    if (*mode < 0) goto L260;
-    if (*mode > 0) goto L220;
-    itermx = *iter;
-    iexact = (*acc >= 0.0) ? 0 : 1;
-    *acc = fabs(*acc);
-    tol = 10.0 * *acc;
-    *iter = 0;
-    ireset = 0;
-    n1 = n + 1;
-    n2 = n1 * n / 2;
-    n3 = n2 + 1;
-    for (i = 0; i < n; ++i) s[i] = 0.0;
-    for (i = 0; i < m; ++i) mu[i] = 0.0;
-L110:
-    ireset = ireset + 1;
-    if (ireset > 5) goto L255;
-    if (S->offload) S->qp_reset = 1;
-    else {
-        for (i = 0; i < n2; ++i) l[i] = 0.0;
-        j = 1;
-        for (i = 1; i <= n; ++i) { l[j - 1] = 1.0; j = j + n1 - i; }
-    }
-L130:
-    *iter = *iter + 1;
-    *mode = 9;
-    if (*iter > itermx) goto L330;
-    dcopy_(n, xl, 1, u, 1);
-    dcopy_(n, xu, 1, v, 1);
-    daxpy_sl(n, -1.0, x, 1, u, 1);
-    daxpy_sl(n, -1.0, x, 1, v, 1);
-    h4 = 1.0;
-    if (S->offload) {
-        *mode = MPC_SLSQP_MODE_QP;          /* the caller solves the QP: box in u, v */
-        goto L330;
-    }
-    lsq_dispatch(m, meq, n, n3, la, l, g, a, c, u, v, s, r, w, iw, mode);
-    goto L136;
-L135:
-    *mode = S->qp_mode;                     /* s and r were written by the caller */
-    S->qp_reset = 0;
-    S->qp_bfgs = 0;
-    if (*mode == 4 || (*mode == 6 && n == meq)) { *mode = MPC_SLSQP_MODE_NEEDS_HOST; goto L330; }
-L136:
-    badlin = 0;
-    if (*mode == 6 && n == meq) *mode = 4;
-    if (*mode == 4) {
-        badlin = 1;
-        for (j = 1; j <= m; ++j) A(j, n1) = (j <= meq) ? -c[j - 1] : MAX(-c[j - 1], 0.0);
-        for (i = 0; i < n; ++i) s[i] = 0.0;
-        h3 = 0.0;
-        g[n1 - 1] = 0.0;
-        l[n3 - 1] = 100.0;
-        s[n1 - 1] = 1.0;
-        u[n1 - 1] = 0.0;
-        v[n1 - 1] = 1.0;
-        incons = 0;
-    L150:
-        lsq_dispatch(m, meq, n1, n3, la, l, g, a, c, u, v, s, r, w, iw, mode);
-        h4 = 1.0 - s[n1 - 1];
-        if (*mode == 4) {
-            l[n3 - 1] = 10.0 * l[n3 - 1];
-            incons = incons + 1;
-            if (incons > 5) goto L330;
-            goto L150;
-        } else if (*mode != 1) goto L330;
-    } else if (*mode != 1) goto L330;
-    if (!S->offload)                        /* offloaded: kept where l lives, it only feeds the BFGS update */
-        for (i = 1; i <= n; ++i) v[i - 1] = g[i - 1] - ddot_sl(m, &A(1, i), 1, r, 1);
-    f0 = f;
-    dcopy_(n, x, 1, x0, 1);
-    gs = ddot_sl(n, g, 1, s, 1);
-    h1 = fabs(gs);
-    h2 = 0.0;
-    for (j = 1; j <= m; ++j) {
-        h3 = (j <= meq) ? c[j - 1] : 0.0;
-        h2 = h2 + MAX(-c[j - 1], h3);
-        h3 = fabs(r[j - 1]);
-        mu[j - 1] = MAX(h3, (mu[j - 1] + h3) / 2.0);
-        h1 = h1 + h3 * fabs(c[j - 1]);
-    }
-    *mode = 0;
-    if (h1 < *acc && h2 < *acc && !badlin && f == f) goto L330;
-    h1 = 0.0;
-    for (j = 1; j <= m; ++j) {
-        h3 = (j <= meq) ? c[j - 1] : 0.0;
-        h1 = h1 + mu[j - 1] * MAX(-c[j - 1], h3);
-    }
-    t0 = f + h1;
-    h3 = gs - h1 * h4;
-    *mode = 8;
-    if (h3 >= 0.0) goto L110;
-    line = 0;
-    alpha = 1.0;
-    if (iexact == 1) { *mode = 8; goto L330; }   /* exact line search is not part of this restatement */
-L190:
-    line = line + 1;
-    h3 = alpha * h3;
-    dscal_sl(n, alpha, s, 1);
-    dcopy_(n, x0, 1, x, 1);
-    daxpy_sl(n, 1.0, s, 1, x, 1);
-    *mode = 1;
-    goto L330;
-L200:
-    if (h1 <= h3 / 10.0 || line > 10) goto L240;
-    alpha = MAX(h3 / (2.0 * (h3 - h1)), alfmin);
-    goto L190;
-L220:
-    t = f;
-    for (j = 1; j <= m; ++j) {
-        h1 = (j <= meq) ? c[j - 1] : 0.0;
-        t = t + mu[j - 1] * MAX(-c[j - 1], h1);
-    }
-    h1 = t - t0;
-    goto L200;
-L240:
-    h3 = 0.0;
-    for (j = 1; j <= m; ++j) {
-        h1 = (j <= meq) ? c[j - 1] : 0.0;
-        h3 = h3 + MAX(-c[j - 1], h1);
-    }
-    if ((fabs(f - f0) < *acc || dnrm2_(n, s, 1) < *acc) && h3 < *acc && !badlin && f == f) *mode = 0;
-    else *mode = -1;
-    goto L330;
-L255:
-    h3 = 0.0;
-    for (j = 1; j <= m; ++j) {
-        h1 = (j <= meq) ? c[j - 1] : 0.0;
-        h3 = h3 + MAX(-c[j - 1], h1);
-    }
-    if ((fabs(f - f0) < tol || dnrm2_(n, s, 1) < tol) && h3 < tol && !badlin && f == f) *mode = 0;
-    else *mode = 8;
-    goto L330;
-L260:
-    if (S->offload) { S->qp_bfgs = 1; goto L130; }
-    if (bfgs_hook) bfgs_hook(m, n, la, l, g, a, r, u, v, s);
-    else mpc_slsqp_bfgs_builtin(m, n, la, l, g, a, r, u, v, s);
-    goto L130;
-L330:
-    S->alpha = alpha; S->f0 = f0; S->gs = gs; S->h1 = h1; S->h2 = h2; S->h3 = h3; S->h4 = h4; S->t = t; S->t0 = t0; S->tol = tol;
-    S->iexact = iexact; S->incons = incons; S->ireset = ireset; S->itermx = itermx; S->line = line;
-    S->n1 = n1; S->n2 = n2; S->n3 = n3;
-#undef A
-}
+#define SLSQP_BODY_FULL 1
+#include "slsqp_body.inc"
+#undef SLSQP_BODY_FULL
 
 /* One reverse-communication call; arguments as scipy.optimize._slsqp.slsqp.  a is column-major (la, n+1). */
 void mpc_slsqp_step(int m, int meq, int la, int n, double *x, double *xl, double *xu, double f, double *c, double *g, double *a,

@@ -1,0 +1,174 @@
+"""Batched SLSQP with every problem resident on the GPU (``mpc_solve_*`` in include/mpc_amd.h).
+
+scipy's driver loop (``_slsqp_py.py:427-456``, called by ``URMPC.compute_control`` at ur_mpc.py:188-200) runs
+on the device from the start point to the solution: Kraft's O(n + m) body as a one-thread-per-problem kernel
+(the text the host core of ``libmpc_slsqp.so`` is compiled from), the evaluations and the BFGS update + QP of
+each round driven by device-side request lists.  This process only enqueues rounds and, every few rounds,
+reads ONE integer per lane (how many problems are unfinished) from pinned memory: no host threads run SLSQP
+logic, nothing is staged across PCIe per iteration.  Results equal the host drivers' bit for bit
+(tests/test_gpu_solve.py::test_resident_driver_equals_host_driver).
+
+A batch is split over up to ``lanes`` independent parts, each with its own stream, context (QP workspace) and
+state, enqueued round-robin from this one thread, so that one part's short kernels fill the CUs another part's
+straggling QP teams leave idle.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import time
+
+import numpy as np
+import torch
+
+from . import _ffi
+from .batch import MpcContext, ScenarioBatch
+from .native_solver import MODE_NEEDS_HOST, active_lanes
+from .solver import BatchSolveResult
+
+
+class _ResidentLane:
+    def __init__(self, ctx: MpcContext, capacity: int):
+        self.ctx = ctx
+        self.cap = cap = int(capacity)
+        p = ctx.params
+        dev = ctx.device
+        self.ws_bytes = int(ctx._lib.mpc_solve_workspace_bytes(p.horizon, cap))
+        self.ws = torch.empty(self.ws_bytes, dtype=torch.uint8, device=dev)
+        self.x0 = torch.empty(cap, p.n, dtype=torch.float64, device=dev)
+        self.x = torch.empty(cap, p.n, dtype=torch.float64, device=dev)
+        self.fun = torch.empty(cap, dtype=torch.float64, device=dev)
+        self.nit = torch.empty(cap, dtype=torch.int32, device=dev)
+        self.status = torch.empty(cap, dtype=torch.int32, device=dev)
+        self.stats = torch.zeros(4, dtype=torch.int32, device=dev)
+        self.left = torch.zeros(2, dtype=torch.int32).pin_memory()      # "unfinished" of the two batches in flight
+        self.events = [torch.cuda.Event(), torch.cuda.Event()]
+        self.stream = torch.cuda.Stream(device=dev)
+
+    def _call(self, fn, *args):
+        _ffi.check(self.ctx._ctx, fn(self.ctx._ctx, *args))
+
+    def begin(self, sc: ScenarioBatch, x0: np.ndarray):
+        ctx, p = self.ctx, self.ctx.params
+        self.sc, self.N = sc, sc.count
+        self.scc = ctx._scen_c(sc)
+        self.bound, self.batches, self.rounds, self.running = self.N, 0, 0, True
+        with torch.cuda.stream(self.stream):
+            self.x0[:self.N].copy_(torch.from_numpy(np.ascontiguousarray(x0)), non_blocking=True)
+            self._call(ctx._lib.mpc_solve_begin, C.byref(self.scc), self.x0.data_ptr(), float(p.ftol), int(p.maxiter),
+                       self.ws.data_ptr(), self.cap, self.ws_bytes, C.c_void_p(self.stream.cuda_stream))
+
+    def enqueue(self, rounds: int):
+        """`rounds` more rounds on the lane's stream; the count of problems unfinished after them lands in pinned
+        memory, followed by an event."""
+        slot = self.batches & 1
+        self._call(self.ctx._lib.mpc_solve_rounds, C.byref(self.scc), self.ws.data_ptr(), self.cap, self.ws_bytes, int(rounds),
+                   int(self.bound), self.left[slot:].data_ptr(), C.c_void_p(self.stream.cuda_stream))
+        self.events[slot].record(self.stream)
+        self.batches += 1
+        self.rounds += rounds
+
+    def check(self):
+        """Wait for the batch before the one just enqueued; its count bounds every later round's lists."""
+        if self.batches < 2:
+            return
+        slot = self.batches & 1                   # the older of the two in flight
+        self.events[slot].synchronize()
+        self.bound = int(self.left[slot])
+        if self.bound == 0:
+            self.running = False
+
+    def finish(self):
+        with torch.cuda.stream(self.stream):
+            self._call(self.ctx._lib.mpc_solve_result, self.N, self.ws.data_ptr(), self.cap, self.ws_bytes, self.x.data_ptr(),
+                       self.fun.data_ptr(), self.nit.data_ptr(), self.status.data_ptr(), self.stats.data_ptr(),
+                       C.c_void_p(self.stream.cuda_stream))
+            N = self.N
+            out = (self.x[:N].cpu().numpy(), self.fun[:N].cpu().numpy(), self.nit[:N].cpu().numpy().astype(int),
+                   self.status[:N].cpu().numpy().astype(int), self.stats.cpu().numpy().astype(int))
+        self.sc = self.scc = None
+        return out
+
+
+class ResidentSLSQP:
+    """Same interface as the other batched drivers (``solve(ScenarioBatch, x0) -> BatchSolveResult``)."""
+
+    def __init__(self, ctx: MpcContext, capacity: int = None, lanes: int = 4, min_per_lane: int = 2048,
+                 rounds_per_check: int = 6):
+        if not ctx.nz_supported():
+            raise ValueError("the driver takes dc/dx in its structured form: the context needs MPC_ALGO_PREFIX")
+        if not 1 <= lanes <= 8:
+            raise ValueError("lanes must be 1..8")
+        self.ctx = ctx
+        self.cap = cap = int(capacity or ctx.max_scenarios)
+        self.min_per_lane = max(1, int(min_per_lane))
+        self.rounds_per_check = max(1, int(rounds_per_check))
+        lanes = max(1, min(lanes, cap // self.min_per_lane))
+        lane_cap = (cap + lanes - 1) // lanes
+        self._ctxs = [ctx] + [MpcContext(ctx.params, lane_cap, ctx.device_index) for _ in range(lanes - 1)]
+        self.lanes = [_ResidentLane(c, lane_cap) for c in self._ctxs]
+        self.threads = 1
+        self._host_fallback = None
+
+    def solve(self, sc: ScenarioBatch, x0: np.ndarray) -> BatchSolveResult:
+        ctx = self.ctx
+        p = ctx.params
+        N, n = sc.count, p.n
+        if N > self.cap:
+            raise ValueError(f"{N} scenarios > capacity {self.cap}")
+        if N == 0:
+            return BatchSolveResult(np.zeros((0, n)), np.zeros(0), np.zeros(0, int), np.zeros(0, int), 0, 0, 0)
+        x0 = np.asarray(x0, dtype=np.float64).reshape(N, n)
+        t_start = time.perf_counter()
+        caller = torch.cuda.current_stream(ctx.device)
+        k = active_lanes(N, len(self.lanes), self.lanes[0].cap, self.min_per_lane)
+        cuts = [(N * i) // k for i in range(k + 1)]
+        lanes = self.lanes[:k]
+        for i, lane in enumerate(lanes):
+            lane.stream.wait_stream(caller)              # the scenarios were written on the caller's stream
+            lane.begin(sc.slice(cuts[i], cuts[i + 1]), x0[cuts[i]:cuts[i + 1]])
+        R = self.rounds_per_check
+        while any(lane.running for lane in lanes):
+            for lane in lanes:
+                if lane.running:
+                    lane.enqueue(R)
+            for lane in lanes:
+                if lane.running:
+                    lane.check()
+        parts = [lane.finish() for lane in lanes]
+        for lane in lanes:
+            caller.wait_stream(lane.stream)
+        x = np.concatenate([r[0] for r in parts])
+        fun = np.concatenate([r[1] for r in parts])
+        nit = np.concatenate([r[2] for r in parts])
+        status = np.concatenate([r[3] for r in parts])
+        stats = np.sum([r[4] for r in parts], axis=0)
+        n_eval, n_eval_fd, n_qp = int(stats[0]), int(stats[1]) + N, int(stats[2])
+        redo = np.nonzero(status == MODE_NEEDS_HOST)[0]
+        if len(redo):                       # inconsistent linearisation somewhere along the way: host-only solve
+            from .native_solver import NativeBatchedSLSQP
+
+            if self._host_fallback is None:
+                self._host_fallback = NativeBatchedSLSQP(ctx, threads=0, capacity=self.cap, groups=1)
+            sub = ctx.gather(sc, torch.from_numpy(redo.astype(np.int32)).to(ctx.device),
+                             ScenarioBatch.empty(ctx.device, len(redo), p.horizon, sc.u_prev is not None))
+            r2 = self._host_fallback.solve(sub, x0[redo])
+            x[redo], fun[redo], nit[redo], status[redo] = r2.x, r2.fun, r2.nit, r2.status
+            n_eval += r2.n_eval
+            n_eval_fd += r2.n_eval_fd
+        res = BatchSolveResult(x=x, fun=fun, nit=nit, status=status, rounds=max(lane.rounds for lane in lanes), n_eval=n_eval,
+                               n_eval_fd=n_eval_fd, t_core=0.0, t_serve=time.perf_counter() - t_start)
+        res.n_qp, res.t_qp, res.n_host_fallback = n_qp, 0.0, len(redo)
+        res.t_wall = time.perf_counter() - t_start
+        return res
+
+    def close(self):
+        self.lanes = []
+        if self._host_fallback is not None:
+            self._host_fallback.close()
+            self._host_fallback = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()

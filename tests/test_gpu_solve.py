@@ -501,3 +501,95 @@ def test_device_qp_driver_equals_host_driver():
         assert (two.n_eval, two.n_eval_fd) == (one.n_eval, one.n_eval_fd)
         assert two.n_qp >= int(one.nit.sum())
         np.testing.assert_array_equal(again.x, one.x[:5])
+
+
+def test_resident_driver_equals_host_driver():
+    """Whole solves resident on the device (mpc_solve_*: Kraft's body as a kernel, device-side request lists, no
+    host SLSQP logic at all): iterates, exit modes, iteration and evaluation counts identical to the host-only
+    driver, which is pinned call by call to scipy's compiled core."""
+    from helpers import host_scenarios
+    from mpc_amd.batch import MpcContext
+    from mpc_amd.device_solver import ResidentSLSQP
+    from mpc_amd.native_solver import NativeBatchedSLSQP
+    from mpc_amd.scenarios import to_device
+
+    for H, count, prev in ((1, 9, False), (3, 200, True), (20, 24, False), (20, 150, True), (32, 6, False)):
+        mp = MpcParams.reference_yaml_defaults(horizon=H)
+        ctx = MpcContext(mp, 256, 0)
+        _, hs = host_scenarios(mp, count, motion="angular", cfg_id=19, with_prev=prev)
+        sc, _ = to_device(ctx, hs)
+        with NativeBatchedSLSQP(ctx, threads=3) as host:
+            one = host.solve(sc, hs.x)
+        with ResidentSLSQP(ctx, lanes=4, min_per_lane=32, rounds_per_check=5) as dev:
+            assert len(dev.lanes) == 4
+            two = dev.solve(sc, hs.x)
+            again = dev.solve(sc.slice(0, 5), hs.x[:5])
+        np.testing.assert_array_equal(two.status, one.status)
+        np.testing.assert_array_equal(two.nit, one.nit)
+        np.testing.assert_array_equal(two.x, one.x)
+        np.testing.assert_array_equal(two.fun, one.fun)
+        assert (two.n_eval, two.n_eval_fd) == (one.n_eval, one.n_eval_fd)
+        assert two.n_qp >= int(one.nit.sum())
+        np.testing.assert_array_equal(again.x, one.x[:5])
+
+
+def test_resident_driver_hands_inconsistent_linearisations_to_the_host():
+    from helpers import host_scenarios
+    from mpc_amd.batch import MpcContext
+    from mpc_amd.device_solver import ResidentSLSQP
+    from mpc_amd.native_solver import NativeBatchedSLSQP
+    from mpc_amd.scenarios import to_device
+
+    mp = MpcParams.reference_yaml_defaults(horizon=3)
+    N = 12
+    ctx = MpcContext(mp, N, 0)
+    _, hs = host_scenarios(mp, N, motion="angular", cfg_id=23)
+    bad = [2, 7]
+    hs.state0[bad, 0] = mp.q_limit + 0.2
+    sc, _ = to_device(ctx, hs)
+    with NativeBatchedSLSQP(ctx, threads=2) as host:
+        one = host.solve(sc, hs.x)
+    with ResidentSLSQP(ctx) as dev:
+        two = dev.solve(sc, hs.x)
+    assert two.n_host_fallback == len(bad)
+    np.testing.assert_array_equal(two.status, one.status)
+    np.testing.assert_array_equal(two.nit, one.nit)
+    np.testing.assert_array_equal(two.x, one.x)
+
+
+def test_qp_step_rejects_an_index_outside_the_state_rows():
+    """mpc_qp_step never addresses state outside [0, rows): such a request gets mode -100 and the valid requests
+    of the same call are served as usual."""
+    import ctypes as C
+
+    from helpers import host_scenarios
+    from mpc_amd import _ffi
+    from mpc_amd.batch import MpcContext
+    from mpc_amd.scenarios import to_device
+
+    mp = MpcParams.reference_yaml_defaults(horizon=3)
+    rows = 4
+    ctx = MpcContext(mp, 8, 0)
+    _, hs = host_scenarios(mp, rows, motion="linear", cfg_id=24)
+    sc, x = to_device(ctx, hs)
+    r = ctx.eval_fd_nz(sc, x)
+    n, m = mp.n, mp.m
+    dev = ctx.device
+    z = lambda *shape: torch.zeros(shape, dtype=torch.float64, device=dev)
+    L, R, V = z(rows, (n + 1) * n // 2 + 1), z(rows, m + 2 * n), z(rows, n)
+    lim = torch.as_tensor(np.tile(mp.v_lim, mp.horizon)).to(dev)
+    index = torch.tensor([1, rows, -3, 2], dtype=torch.int32, device=dev)
+    flags = torch.ones(4, dtype=torch.int32, device=dev)             # reset the factor, then solve
+    lo, hi = (-lim - x[[1, 0, 0, 2]]).contiguous(), (lim - x[[1, 0, 0, 2]]).contiguous()
+    s_out, r_out = z(4, n), z(4, m)
+    mode = torch.zeros(4, dtype=torch.int32, device=dev)
+    before = (L.clone(), R.clone(), V.clone())
+    _ffi.check(ctx._ctx, ctx._lib.mpc_qp_step(ctx._ctx, 4, rows, index.data_ptr(), flags.data_ptr(), lo.data_ptr(), hi.data_ptr(),
+                                              z(4, n).data_ptr(), L.data_ptr(), r.grad.data_ptr(), r.con.data_ptr(),
+                                              r.con_jac_nz.data_ptr(), R.data_ptr(), V.data_ptr(), s_out.data_ptr(),
+                                              r_out.data_ptr(), mode.data_ptr(), ctx._stream()))
+    torch.cuda.synchronize()
+    assert mode.cpu().tolist()[1:3] == [-100, -100] and mode[0].item() == 1 and mode[3].item() == 1
+    for k in (0, 3):                                                  # rows that no request named are untouched
+        assert torch.equal(L[k], before[0][k]) and torch.equal(R[k], before[1][k]) and torch.equal(V[k], before[2][k])
+    assert float(L[1].abs().sum()) > 0 and float(s_out[0].abs().sum()) > 0 and float(s_out[1].abs().sum()) == 0
