@@ -82,15 +82,25 @@ __global__ void __launch_bounds__(mpck::kQpThreads, MPC_QP_WAVES)
 qp_step_kernel(int H, int count, int rows, const int32_t *__restrict__ index, const int32_t *__restrict__ count_dev,
                const int32_t *__restrict__ flags, const double *__restrict__ lo, const double *__restrict__ hi, const double *s_in,
                double *L, const double *__restrict__ G, const double *__restrict__ C, const double *__restrict__ NZ, double *R,
-               double *V, double *s_out, double *__restrict__ r_out, int32_t *__restrict__ mode, double *work, int *iwork,
-               size_t wd, size_t wi)
+               double *V, double *s_out, double *__restrict__ r_out, int32_t *__restrict__ mode, int32_t *head, double *work,
+               int *iwork, size_t wd, size_t wi)
 {
     const int n = 6 * H, m = 12 * (H + 1), mg = m + 2 * n, nzc = 6 * H + 3 * H * (H + 1);
     const int ldl = (n + 1) * n / 2 + 1;
     const lsqspmd::Work W = team_work<kLds>(work, iwork, wd, wi, n, m);
     const HipTeam T;
     if (kRows) count = *count_dev;
-    for (int k = (int)blockIdx.x; k < count; k += (int)gridDim.x) {
+    // kRows: the teams take requests from a shared queue (QPs differ a lot in cost: a fixed share per team would leave
+    // most teams waiting for the slowest); every team leaves the loop at its first k >= count.
+    for (int turn = 0;; ++turn) {
+        int k = (int)blockIdx.x + turn * (int)gridDim.x;
+        if (kRows) {
+            if (threadIdx.x == 0) W.isc[15] = atomicAdd(head, 1);
+            __syncthreads();
+            k = W.isc[15];
+            __syncthreads();
+        }
+        if (k >= count) break;
         const int pi = index[k];
         const size_t q = kRows ? (size_t)pi : (size_t)k;        // row of the per-request arrays
         if (pi < 0 || pi >= rows) {                              // never address state outside the caller's rows
@@ -157,7 +167,7 @@ template <bool kRows>
 hipError_t launch_qp_step_any(int H, int count, int teams, int rows, const int32_t *index, const int32_t *count_dev,
                               const int32_t *flags, const double *lo, const double *hi, const double *s_in, double *L, const double *G,
                               const double *C, const double *NZ, double *R, double *V, double *s_out, double *r_out, int32_t *mode,
-                              double *work, int *iwork, hipStream_t stream)
+                              int32_t *head, double *work, int *iwork, hipStream_t stream)
 {
     const size_t lds = lds_bytes(H);
     if (lds) {
@@ -165,11 +175,11 @@ hipError_t launch_qp_step_any(int H, int count, int teams, int rows, const int32
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL((qp_step_kernel<true, kRows>), dim3((unsigned)teams), dim3(kQpThreads), lds, stream, H, count, rows, index,
-                           count_dev, flags, lo, hi, s_in, L, G, C, NZ, R, V, s_out, r_out, mode, work, iwork, qp_work_doubles(H),
+                           count_dev, flags, lo, hi, s_in, L, G, C, NZ, R, V, s_out, r_out, mode, head, work, iwork, qp_work_doubles(H),
                            qp_work_ints(H));
     } else {
         hipLaunchKernelGGL((qp_step_kernel<false, kRows>), dim3((unsigned)teams), dim3(kQpThreads), 0, stream, H, count, rows, index,
-                           count_dev, flags, lo, hi, s_in, L, G, C, NZ, R, V, s_out, r_out, mode, work, iwork, qp_work_doubles(H),
+                           count_dev, flags, lo, hi, s_in, L, G, C, NZ, R, V, s_out, r_out, mode, head, work, iwork, qp_work_doubles(H),
                            qp_work_ints(H));
     }
     return hipGetLastError();
@@ -182,7 +192,7 @@ hipError_t launch_qp_step(int H, int count, int teams, int rows, const int32_t *
                           hipStream_t stream)
 {
     return launch_qp_step_any<false>(H, count, teams, rows, index, nullptr, flags, lo, hi, s_in, L, G, C, NZ, R, V, s_out, r_out, mode,
-                                     work, iwork, stream);
+                                     nullptr, work, iwork, stream);
 }
 
 hipError_t launch_qp_step_rows(int H, int teams, int rows, const RowList &list, const int32_t *flags, const double *lo,
@@ -190,9 +200,10 @@ hipError_t launch_qp_step_rows(int H, int teams, int rows, const RowList &list, 
                                double *R, double *V, int32_t *mode, double *work, int *iwork, hipStream_t stream)
 {
     if (list.bound <= 0) return hipSuccess;
+    if (list.head == nullptr) return hipErrorInvalidValue;
     const int t = teams < list.bound ? teams : list.bound;
     return launch_qp_step_any<true>(H, list.bound, t, rows, list.list, list.count, flags, lo, hi, S, L, G, C, NZ, R, V, S, nullptr,
-                                    mode, work, iwork, stream);
+                                    mode, list.head, work, iwork, stream);
 }
 
 size_t qp_work_doubles(int H) { return lsqspmd::work_doubles(6 * H, 12 * (H + 1), kQpThreads); }

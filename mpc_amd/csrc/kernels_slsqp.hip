@@ -54,7 +54,7 @@ __device__ __forceinline__ double dnrm2_(int n, const double *dx, int)
     return scale * sqrt(ssq);
 }
 
-__device__ void slsqp_body_device(int m, int meq, int la, int n, double *x, const double *xl, const double *xu, double f,
+__device__ __forceinline__ void slsqp_body_device(int m, int meq, int la, int n, double *x, const double *xl, const double *xu, double f,
                                   const double *c, const double *g, double *a, double *acc, int *iter, int *mode, const double *r,
                                   double *l, double *x0, double *mu, double *s, double *u, double *v, double *w, int *iw,
                                   slsqp_state *S)
@@ -81,9 +81,9 @@ SolveWorkspace carve_solve_workspace(void *base, int H, int rows)
     W.ST = reinterpret_cast<slsqp_state *>(take(R * (sizeof(slsqp_state) / sizeof(double))));
     int32_t *i = reinterpret_cast<int32_t *>(d);
     auto itake = [&](size_t count) { int32_t *p = i; i += (count + 63) & ~size_t(63); return p; };
-    W.MODE = itake(R); W.ITER = itake(R); W.QPMODE = itake(R); W.QPFLAGS = itake(R); W.DONE = itake(R);
-    W.LIST_F = itake(R); W.LIST_G = itake(R); W.LIST_Q = itake(R);
-    W.counters = itake(16);
+    W.MODE = itake(R); W.ITER = itake(R); W.QPMODE = itake(R); W.QPFLAGS = itake(R);
+    for (int h = 0; h < 2; ++h) { W.LIST_F[h] = itake(R); W.LIST_G[h] = itake(R); W.LIST_Q[h] = itake(R); }
+    W.counters = itake(32);
     W.bytes = (size_t)(reinterpret_cast<char *>(i) - static_cast<char *>(base));
     return W;
 }
@@ -109,7 +109,9 @@ __global__ void solve_begin_kernel(const mpc_params P, SolveWorkspace W, int cou
         W.lb[idx] = -lim;
         W.ub[idx] = lim;
     }
-    if (idx < 16) W.counters[idx] = 0;
+    // lists of "round -1" (slot 0): every problem is waiting for its first call of the body
+    if (idx < 32) W.counters[idx] = (idx == 0 || idx == 3) ? count : 0;
+    if (idx < (size_t)count) W.LIST_F[0][idx] = (int32_t)idx;
     if (idx >= (size_t)count * n) return;
     const int i = (int)(idx % n);
     double lim = P.v_lim[0];
@@ -127,65 +129,92 @@ __global__ void solve_begin_kernel(const mpc_params P, SolveWorkspace W, int cou
         W.MODE[p] = 0;
         W.QPMODE[p] = 0;
         W.QPFLAGS[p] = 0;
-        W.DONE[p] = 0;
         slsqp_state z = {};
         z.offload = 1;
         W.ST[p] = z;
     }
 }
 
-// One call of the body for every unfinished problem; what it asks for next goes to the round's request lists.
-// counters: [0] f requests, [1] derivative requests, [2] QP requests, [3] unfinished problems of this round (the caller
-// zeroes [0..3] before the launch); [4..6] running totals of the three kinds.
-__global__ __launch_bounds__(64) void solve_body_kernel(int H, SolveWorkspace W, int count)
+// One call of the body for every unfinished problem, one wavefront per problem: the problems are those on the
+// previous round's three request lists (slot `old` of the double-buffered lists and counters; they were served since),
+// the vectors the body reads are staged in LDS with coalesced loads, the first lane runs the body on them, the team
+// writes back what it changed.  What the problem asks for next goes to the new slot's lists.
+// counters, per slot s at [8 s ..]: +0 f requests, +1 derivative requests, +2 QP requests, +3 their total (= problems
+// still unfinished), +4 the QP kernel's work-queue head (the caller zeroes the new slot before the launch);
+// [16..18] running totals of the three kinds.
+__global__ __launch_bounds__(64) void solve_body_kernel(int H, SolveWorkspace W, int old)
 {
-    const int p = (int)(blockIdx.x * blockDim.x + threadIdx.x);
-    if (p >= count) return;
-    if (W.DONE[p]) return;
-    int mode = W.MODE[p];
-    const int n = 6 * H, m = 12 * (H + 1), mg = m + 2 * n;
-    slsqp_state S = W.ST[p];
-    if (mode == MPC_SLSQP_MODE_QP) S.qp_mode = W.QPMODE[p];
-    int iter = W.ITER[p];
-    double acc = W.ACC[p];
-    double *x = W.X + (size_t)p * n;
-    slsqp_body_device(m, 0, m, n, x, W.lb, W.ub, W.F[p], W.C + (size_t)p * m, W.G + (size_t)p * n, nullptr, &acc, &iter, &mode,
-                      W.RM + (size_t)p * mg, nullptr, W.X0 + (size_t)p * n, W.MU + (size_t)p * m, W.S + (size_t)p * n,
-                      W.LO + (size_t)p * n, W.HI + (size_t)p * n, nullptr, nullptr, &S);
-    W.ST[p] = S;
-    W.ITER[p] = iter;
-    W.ACC[p] = acc;
-    W.MODE[p] = mode;
-    if (mode == 1 || mode == -1) {
-        double *xe = W.XE + (size_t)p * n;                      // the point to evaluate, inside the box (_clip_x_for_func)
-        for (int i = 0; i < n; ++i) {
-            double v = x[i];
-            v = v < W.lb[i] ? W.lb[i] : v;
-            v = v > W.ub[i] ? W.ub[i] : v;
-            xe[i] = v;
+    extern __shared__ double body_lds[];
+    const int32_t *co = W.counters + 8 * old;
+    int32_t *cn = W.counters + 8 * (1 - old);
+    const int cF = co[0], cG = co[1], cQ = co[2];
+    int k = (int)blockIdx.x, p;
+    if (k < cF) p = W.LIST_F[old][k];
+    else if ((k -= cF) < cG) p = W.LIST_G[old][k];
+    else if ((k -= cG) < cQ) p = W.LIST_Q[old][k];
+    else return;
+    const int n = 6 * H, m = 12 * (H + 1), mg = m + 2 * n, lane = (int)threadIdx.x;
+    double *x = body_lds, *x0 = x + n, *s = x0 + n, *u = s + n, *v = u + n, *g = v + n, *c = g + n, *mu = c + m, *r = mu + m;
+    double *gx = W.X + (size_t)p * n, *gx0 = W.X0 + (size_t)p * n, *gs = W.S + (size_t)p * n, *gmu = W.MU + (size_t)p * m;
+    {
+        const double *gg = W.G + (size_t)p * n, *gc = W.C + (size_t)p * m, *gr = W.RM + (size_t)p * mg;
+        for (int i = lane; i < n; i += 64) { x[i] = gx[i]; x0[i] = gx0[i]; s[i] = gs[i]; g[i] = gg[i]; }
+        for (int i = lane; i < m; i += 64) { c[i] = gc[i]; mu[i] = gmu[i]; r[i] = gr[i]; }
+    }
+    __syncthreads();
+    if (lane == 0) {
+        int mode = W.MODE[p];
+        slsqp_state S = W.ST[p];
+        if (mode == MPC_SLSQP_MODE_QP) S.qp_mode = W.QPMODE[p];
+        int iter = W.ITER[p];
+        double acc = W.ACC[p];
+        slsqp_body_device(m, 0, m, n, x, W.lb, W.ub, W.F[p], c, g, nullptr, &acc, &iter, &mode, r, nullptr, x0, mu, s, u, v, nullptr,
+                          nullptr, &S);
+        W.ST[p] = S;
+        W.ITER[p] = iter;
+        W.ACC[p] = acc;
+        W.MODE[p] = mode;
+        int slot = -1;
+        if (mode == 1 || mode == -1) {
+            const int kind = mode == 1 ? 0 : 1;
+            slot = atomicAdd(&cn[kind], 1);
+            (kind == 0 ? W.LIST_F : W.LIST_G)[1 - old][slot] = p;
+            atomicAdd(&W.counters[16 + kind], 1);
+            atomicAdd(&cn[3], 1);
+        } else if (mode == MPC_SLSQP_MODE_QP) {
+            W.QPFLAGS[p] = (S.qp_reset ? 1 : 0) | (S.qp_bfgs ? 2 : 0);
+            slot = atomicAdd(&cn[2], 1);
+            W.LIST_Q[1 - old][slot] = p;
+            atomicAdd(&W.counters[18], 1);
+            atomicAdd(&cn[3], 1);
+        }                                                           // else: finished, MODE[p] is the exit mode
+        reinterpret_cast<int *>(body_lds + 6 * n + 3 * m)[0] = mode;
+    }
+    __syncthreads();
+    const int mode = reinterpret_cast<const int *>(body_lds + 6 * n + 3 * m)[0];
+    for (int i = lane; i < n; i += 64) { gx[i] = x[i]; gx0[i] = x0[i]; gs[i] = s[i]; }
+    for (int i = lane; i < m; i += 64) gmu[i] = mu[i];
+    if (mode == MPC_SLSQP_MODE_QP) {
+        double *gu = W.LO + (size_t)p * n, *gv = W.HI + (size_t)p * n;
+        for (int i = lane; i < n; i += 64) { gu[i] = u[i]; gv[i] = v[i]; }
+    } else if (mode == 1 || mode == -1) {
+        double *xe = W.XE + (size_t)p * n;                          // the point to evaluate, inside the box (_clip_x_for_func)
+        for (int i = lane; i < n; i += 64) {
+            double t = x[i];
+            t = t < W.lb[i] ? W.lb[i] : t;
+            t = t > W.ub[i] ? W.ub[i] : t;
+            xe[i] = t;
         }
-        const int kind = mode == 1 ? 0 : 1;
-        const int k = atomicAdd(&W.counters[kind], 1);
-        (kind == 0 ? W.LIST_F : W.LIST_G)[k] = p;
-        atomicAdd(&W.counters[4 + kind], 1);
-        atomicAdd(&W.counters[3], 1);
-    } else if (mode == MPC_SLSQP_MODE_QP) {
-        W.QPFLAGS[p] = (S.qp_reset ? 1 : 0) | (S.qp_bfgs ? 2 : 0);
-        const int k = atomicAdd(&W.counters[2], 1);
-        W.LIST_Q[k] = p;
-        atomicAdd(&W.counters[6], 1);
-        atomicAdd(&W.counters[3], 1);
-    } else {
-        W.DONE[p] = 1;                                          // MODE[p] is the exit mode (0 = converged)
     }
 }
 
-__global__ void solve_result_kernel(int H, SolveWorkspace W, int count, double *__restrict__ x, double *__restrict__ fun,
-                                    int32_t *__restrict__ nit, int32_t *__restrict__ status, int32_t *__restrict__ stats)
+__global__ void solve_result_kernel(int H, SolveWorkspace W, int count, int slot, double *__restrict__ x,
+                                    double *__restrict__ fun, int32_t *__restrict__ nit, int32_t *__restrict__ status,
+                                    int32_t *__restrict__ stats)
 {
     const int n = 6 * H;
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx < 4 && stats != nullptr) stats[idx] = idx < 3 ? W.counters[4 + idx] : W.counters[3];
+    if (idx < 4 && stats != nullptr) stats[idx] = idx < 3 ? W.counters[16 + idx] : W.counters[8 * slot + 3];
     if (idx >= (size_t)count * n) return;
     x[idx] = W.X[idx];
     if (idx % n == 0) {
@@ -213,20 +242,26 @@ hipError_t launch_solve_begin(const mpc_params &P, const SolveWorkspace &W, int 
     return hipGetLastError();
 }
 
-hipError_t launch_solve_body(int H, const SolveWorkspace &W, int count, hipStream_t stream)
+hipError_t launch_solve_body(int H, const SolveWorkspace &W, int bound, int old_slot, hipStream_t stream)
 {
-    hipError_t e = hipMemsetAsync(W.counters, 0, 4 * sizeof(int32_t), stream);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(solve_body_kernel, dim3((unsigned)((count + 63) / 64)), dim3(64), 0, stream, H, W, count);
+    hipError_t e = hipMemsetAsync(W.counters + 8 * (1 - old_slot), 0, 8 * sizeof(int32_t), stream);
+    if (e != hipSuccess || bound <= 0) return e;
+    const size_t lds = sizeof(double) * (size_t)(6 * 6 * H + 3 * 12 * (H + 1) + 2);
+    if (lds > 48 * 1024) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(solve_body_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(solve_body_kernel, dim3((unsigned)bound), dim3(64), lds, stream, H, W, old_slot);
     return hipGetLastError();
 }
 
-hipError_t launch_solve_result(int H, const SolveWorkspace &W, int count, double *x, double *fun, int32_t *nit, int32_t *status,
-                               int32_t *stats, hipStream_t stream)
+hipError_t launch_solve_result(int H, const SolveWorkspace &W, int count, int slot, double *x, double *fun, int32_t *nit,
+                               int32_t *status, int32_t *stats, hipStream_t stream)
 {
     const size_t total = (size_t)count * 6 * H;
-    hipLaunchKernelGGL(solve_result_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, H, W, count, x, fun, nit,
-                       status, stats);
+    hipLaunchKernelGGL(solve_result_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, H, W, count, slot, x, fun,
+                       nit, status, stats);
     return hipGetLastError();
 }
 

@@ -316,59 +316,97 @@ SPMD_HD int nnls(const Team &T, const Work &W, int mrow, int ncol, int mg, doubl
         PAR_FOR(T, r, npp1, m + 1) AT(r, j) = 0.0;         // rows npp1..m of the new column
         if (T.tid() == 0) w[j - 1] = 0.0;
         T.sync();
-        // ---- steps six to eleven (thread 0): solve, step length, possibly drop columns
-        if (T.tid() == 0) {
-            int status = 0;          // 0: back to L110, 3: iteration limit / empty set
-            int jj = 0;
-            for (;;) {
-                // L180: solve the triangular system for z
-                for (int ip = nsetp; ip >= 1; --ip) {
-                    if (ip != nsetp) {
-                        const double zf = -z[ip];
-                        if (zf != 0.0) {
-                            int r = 1;
-                            for (; r + 7 <= ip; r += 8) {              // independent entries: loads first
-                                double av[8];
-                                SPMD_UNROLL
-                                for (int q = 0; q < 8; ++q) av[q] = AT(r + q, jj);
-                                SPMD_UNROLL
-                                for (int q = 0; q < 8; ++q) z[r - 1 + q] = z[r - 1 + q] + zf * av[q];
-                            }
-                            for (; r <= ip; ++r) z[r - 1] = z[r - 1] + zf * AT(r, jj);
+        // ---- steps six to eleven: solve, step length, possibly drop columns.  The arithmetic is the serial text's,
+        //      entry for entry; what runs in parallel are the entries that do not depend on each other: the rows of one
+        //      elimination step of the triangular solve (on the team's first wavefront, whose LDS traffic needs no
+        //      workgroup barrier) and the columns of one Givens rotation (whole team).
+        int failed = 0;
+        for (;;) {
+            // L180: solve the triangular system for z.  Row r takes the term of row k > r in the order k = nsetp,
+            // nsetp - 1, ..., and is divided by its pivot once row r + 1 is final: one step per row, the rows above it
+            // in parallel.  The pivots are fetched first, all at once, and the columns a panel of eight steps needs are
+            // fetched together before its first step (the matrix lives in global memory: one latency per panel).
+            const int wl = T.size() < 64 ? T.size() : 64;
+            if (T.tid() < wl) {
+                for (int ip = 1 + T.tid(); ip <= nsetp; ip += wl) W.piv[ip - 1] = AT(ip, index[ip - 1]);
+                T.wave_sync();
+                constexpr int P = 8;
+                const int r0 = 1 + T.tid(), r1 = r0 + wl;
+                for (int top = nsetp; top >= 1; top -= P) {
+                    double v0[P], v1[P];
+                    SPMD_UNROLL
+                    for (int q = 0; q < P; ++q) {
+                        const int ip = top - q;
+                        v0[q] = 0.0; v1[q] = 0.0;
+                        if (ip >= 1 && ip != nsetp) {
+                            const int col = index[ip];
+                            if (r0 <= ip) v0[q] = AT(r0, col);
+                            if (r1 <= ip) v1[q] = AT(r1, col);
                         }
                     }
-                    jj = index[ip - 1];
-                    z[ip - 1] = z[ip - 1] / AT(ip, jj);
+                    SPMD_UNROLL
+                    for (int q = 0; q < P; ++q) {
+                        const int ip = top - q;
+                        if (ip >= 1) {
+                            if (ip != nsetp) {
+                                const double zf = -z[ip];
+                                if (zf != 0.0) {
+                                    if (r0 <= ip) z[r0 - 1] = z[r0 - 1] + zf * v0[q];
+                                    if (r1 <= ip) z[r1 - 1] = z[r1 - 1] + zf * v1[q];
+                                    const int col = index[ip];
+                                    for (int r = r1 + wl; r <= ip; r += wl) z[r - 1] = z[r - 1] + zf * AT(r, col);
+                                }
+                                T.wave_sync();
+                            }
+                            if (T.tid() == 0) z[ip - 1] = z[ip - 1] / W.piv[ip - 1];
+                            T.wave_sync();
+                        }
+                    }
                 }
-                iter = iter + 1;
-                if (iter > itmax) { status = 3; break; }
-                double alpha = 1.0;
-                jj = 0;
-                for (int ip = 1; ip <= nsetp; ++ip) {
-                    if (z[ip - 1] > 0.0) continue;
-                    const int l = index[ip - 1];
-                    const double t = -x[l - 1] / (z[ip - 1] - x[l - 1]);
-                    if (alpha < t) continue;
-                    alpha = t;
-                    jj = ip;
+                if (T.tid() == 0) {
+                    int status = 0, jj = 0;      // 0: back to L110, 1: drop columns starting at position jj, 3: give up
+                    iter = iter + 1;
+                    if (iter > itmax) status = 3;
+                    else {
+                        double alpha = 1.0;
+                        for (int ip = 1; ip <= nsetp; ++ip) {
+                            if (z[ip - 1] > 0.0) continue;
+                            const int l = index[ip - 1];
+                            const double t = -x[l - 1] / (z[ip - 1] - x[l - 1]);
+                            if (alpha < t) continue;
+                            alpha = t;
+                            jj = ip;
+                        }
+                        for (int ip = 1; ip <= nsetp; ++ip) {
+                            const int l = index[ip - 1];
+                            x[l - 1] = (1.0 - alpha) * x[l - 1] + alpha * z[ip - 1];
+                        }
+                        status = jj == 0 ? 0 : 1;
+                    }
+                    W.isc[2] = status;
+                    W.isc[3] = iter;
+                    W.isc[7] = jj;
                 }
-                for (int ip = 1; ip <= nsetp; ++ip) {
-                    const int l = index[ip - 1];
-                    x[l - 1] = (1.0 - alpha) * x[l - 1] + alpha * z[ip - 1];
-                }
-                if (jj == 0) break;                       // back to L110
-                int i = index[jj - 1];
-                int emptied = 0;
-                for (;;) {
-                    // L250: move column i out of the set, restore the triangle with Givens rotations
-                    x[i - 1] = 0.0;
-                    jj = jj + 1;
-                    for (int jc = jj; jc <= nsetp; ++jc) {
-                        const int ii = index[jc - 1];
+            }
+            T.sync();
+            iter = W.isc[3];
+            if (W.isc[2] == 3) { failed = 1; break; }
+            if (W.isc[2] == 0) break;                         // back to L110
+            int jj = W.isc[7];
+            int i = index[jj - 1];
+            int emptied = 0;
+            for (;;) {
+                // L250: move column i out of the set, restore the triangle with Givens rotations
+                T.sync();                                     // everyone has read the scalars of the previous pass
+                if (T.tid() == 0) x[i - 1] = 0.0;
+                jj = jj + 1;
+                for (int jc = jj; jc <= nsetp; ++jc) {
+                    const int ii = index[jc - 1];
+                    if (T.tid() == 0) {
                         index[jc - 2] = ii;
                         double da = AT(jc - 1, ii), db = AT(jc, ii), c, s;
                         {
-                            double roe = db, r, zq;
+                            double roe = db, r;
                             if (fabs(da) > fabs(db)) roe = da;
                             const double scale = fabs(da) + fabs(db);
                             if (scale == 0.0) { c = 1.0; s = 0.0; r = 0.0; }
@@ -378,53 +416,55 @@ SPMD_HD int nnls(const Team &T, const Work &W, int mrow, int ncol, int mg, doubl
                                 c = da / r;
                                 s = db / r;
                             }
-                            zq = s;
-                            if (fabs(c) > 0.0 && fabs(c) <= s) zq = 1.0 / c;
                             da = r;
-                            db = zq;
                         }
-                        AT(jc - 1, ii) = da;
-                        AT(jc, ii) = db;
-                        const double t = AT(jc - 1, ii);
-                        for (int q = 1; q <= ncol; ++q) {   // rows jc-1 and jc of every column
+                        W.sc[8] = c; W.sc[9] = s; W.sc[10] = da;
+                        const double dx = b[jc - 2], dy = b[jc - 1];
+                        const double tt = c * dx + s * dy;
+                        b[jc - 1] = c * dy - s * dx;
+                        b[jc - 2] = tt;
+                    }
+                    T.sync();
+                    const double c = W.sc[8], s = W.sc[9];
+                    PAR_FOR(T, q, 1, ncol + 1) {              // rows jc-1 and jc of every column
+                        if (q == ii) {                        // the rotated pair itself: (r, 0)
+                            AT(jc - 1, q) = W.sc[10];
+                            AT(jc, q) = 0.0;
+                        } else {
                             const double dx = AT(jc - 1, q), dy = AT(jc, q);
                             const double tt = c * dx + s * dy;
                             AT(jc, q) = c * dy - s * dx;
                             AT(jc - 1, q) = tt;
                         }
-                        AT(jc - 1, ii) = t;
-                        AT(jc, ii) = 0.0;
-                        {
-                            const double dx = b[jc - 2], dy = b[jc - 1];
-                            const double tt = c * dx + s * dy;
-                            b[jc - 1] = c * dy - s * dx;
-                            b[jc - 2] = tt;
+                    }
+                    T.sync();
+                }
+                npp1 = nsetp;
+                nsetp = nsetp - 1;
+                iz1 = iz1 - 1;
+                if (T.tid() == 0) {
+                    index[iz1 - 1] = i;
+                    int flag = 0, pos = 0, col = 0;           // 0: feasible again, 1: drop the column at pos, 2: set is empty
+                    if (nsetp <= 0) flag = 2;
+                    else {
+                        for (pos = 1; pos <= nsetp; ++pos) {
+                            col = index[pos - 1];
+                            if (x[col - 1] <= 0.0) { flag = 1; break; }
                         }
                     }
-                    npp1 = nsetp;
-                    nsetp = nsetp - 1;
-                    iz1 = iz1 - 1;
-                    index[iz1 - 1] = i;
-                    if (nsetp <= 0) { emptied = 1; break; }
-                    int again = 0;
-                    for (jj = 1; jj <= nsetp; ++jj) {
-                        i = index[jj - 1];
-                        if (x[i - 1] <= 0.0) { again = 1; break; }
-                    }
-                    if (!again) break;
+                    W.isc[12] = flag; W.isc[7] = pos; W.isc[13] = col;
                 }
-                if (emptied) { status = 3; break; }
-                for (int r = 0; r < m; ++r) z[r] = b[r];
+                T.sync();
+                if (W.isc[12] == 2) { emptied = 1; break; }
+                if (W.isc[12] == 0) break;
+                jj = W.isc[7];
+                i = W.isc[13];
             }
-            W.isc[2] = status;
-            W.isc[3] = iter;
-            W.isc[4] = iz1;
-            W.isc[5] = nsetp;
-            W.isc[6] = npp1;
+            if (emptied) { failed = 1; break; }
+            PAR_FOR(T, r, 0, m) z[r] = b[r];
+            T.sync();
         }
-        T.sync();
-        iter = W.isc[3]; iz1 = W.isc[4]; nsetp = W.isc[5]; npp1 = W.isc[6];
-        if (W.isc[2] == 3) { mode = 3; break; }
+        if (failed) { mode = 3; break; }
     }
     // ---- L280
     if (T.tid() == 0) {

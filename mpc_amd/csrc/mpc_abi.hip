@@ -26,6 +26,8 @@ struct mpc_ctx {
     double *d_qp_work = nullptr;  // mpc_qp_solve: workspace of the resident workgroups (allocated on first use)
     int *d_qp_iwork = nullptr;
     int qp_teams = 0;
+    const void *solve_ws = nullptr;   // mpc_solve_*: the workspace mpc_solve_begin set up, and which of its two
+    int solve_slot = 0;               // list/counter slots holds the latest round's requests
     double *d_static = nullptr;   // this device's copy of the file-scope `scratch` array (mpc_eval_fd_static)
     char err[512] = {0};
 };
@@ -494,6 +496,8 @@ int mpc_solve_begin(mpc_ctx *ctx, const mpc_scenarios *sc, const double *x0, dou
     MPC_HIP(ctx, mpck::launch_solve_begin(ctx->params, W, sc->count, x0, acc, maxiter, st));
     // mode 0 on entry: f, c, grad f and dc/dx at the (clipped) start point for everyone (SLSQP:419-425)
     MPC_HIP(ctx, mpck::launch_prefix_nz(ctx->params, ctx->d_decay, *sc, W.XE, W.F, W.G, W.C, W.NZ, st));
+    ctx->solve_ws = ws;
+    ctx->solve_slot = 0;
     return MPC_OK;
 }
 
@@ -507,18 +511,22 @@ int mpc_solve_rounds(mpc_ctx *ctx, const mpc_scenarios *sc, void *ws, int rows, 
         return fail(ctx, MPC_ERR_INVALID_ARG, "state0/target/base_traj/Jc must be non-NULL");
     if (rounds < 0 || bound < 0) return fail(ctx, MPC_ERR_INVALID_ARG, "rounds and bound must not be negative");
     if (sc->count == 0 || rounds == 0) return MPC_OK;
-    if (!ctx->d_qp_work) return fail(ctx, MPC_ERR_INVALID_ARG, "mpc_solve_begin has not run on this context");
+    if (!ctx->d_qp_work || ctx->solve_ws != ws)
+        return fail(ctx, MPC_ERR_INVALID_ARG, "mpc_solve_begin has not run on this context with this workspace");
     if (bound > sc->count) bound = sc->count;
     hipStream_t st = static_cast<hipStream_t>(stream);
     MPC_HIP(ctx, hipSetDevice(ctx->device));
     const mpck::SolveWorkspace W = mpck::carve_solve_workspace(ws, ctx->horizon, rows);
-    mpck::RowList lf, lg, lq;
-    lf.list = W.LIST_F; lf.count = W.counters + 0; lf.bound = bound;
-    lg.list = W.LIST_G; lg.count = W.counters + 1; lg.bound = bound;
-    lq.list = W.LIST_Q; lq.count = W.counters + 2; lq.bound = bound;
     for (int r = 0; r < rounds; ++r) {
-        MPC_HIP(ctx, mpck::launch_solve_body(ctx->horizon, W, sc->count, st));
+        const int old = ctx->solve_slot, cur = 1 - old;
+        MPC_HIP(ctx, mpck::launch_solve_body(ctx->horizon, W, bound, old, st));
+        ctx->solve_slot = cur;
         if (bound == 0) continue;
+        mpck::RowList lf, lg, lq;
+        lf.list = W.LIST_F[cur]; lf.count = W.counters + 8 * cur + 0; lf.bound = bound;
+        lg.list = W.LIST_G[cur]; lg.count = W.counters + 8 * cur + 1; lg.bound = bound;
+        lq.list = W.LIST_Q[cur]; lq.count = W.counters + 8 * cur + 2; lq.bound = bound;
+        lq.head = W.counters + 8 * cur + 4;
         // f and c where the line search asked for them (SLSQP:434-436)
         MPC_HIP(ctx, mpck::launch_prefix_rows(ctx->params, ctx->d_decay, *sc, W.XE, W.F, nullptr, W.C, nullptr, lf, st));
         // grad f and dc/dx at the accepted point (SLSQP:438-440); f and c there are already in place
@@ -527,7 +535,8 @@ int mpc_solve_rounds(mpc_ctx *ctx, const mpc_scenarios *sc, void *ws, int rows, 
         MPC_HIP(ctx, mpck::launch_qp_step_rows(ctx->horizon, ctx->qp_teams, rows, lq, W.QPFLAGS, W.LO, W.HI, W.S, W.L, W.G, W.C, W.NZ,
                                                W.RM, W.V, W.QPMODE, ctx->d_qp_work, ctx->d_qp_iwork, st));
     }
-    if (unfinished) MPC_HIP(ctx, hipMemcpyAsync(unfinished, W.counters + 3, sizeof(int32_t), hipMemcpyDefault, st));
+    if (unfinished)
+        MPC_HIP(ctx, hipMemcpyAsync(unfinished, W.counters + 8 * ctx->solve_slot + 3, sizeof(int32_t), hipMemcpyDefault, st));
     return MPC_OK;
 }
 
@@ -538,9 +547,11 @@ int mpc_solve_result(mpc_ctx *ctx, int count, void *ws, int rows, size_t ws_byte
     if (rc) return rc;
     if (count == 0) return MPC_OK;
     if (!x || !fun || !nit || !status) return fail(ctx, MPC_ERR_INVALID_ARG, "x/fun/nit/status must be non-NULL");
+    if (ctx->solve_ws != ws) return fail(ctx, MPC_ERR_INVALID_ARG, "mpc_solve_begin has not run on this context with this workspace");
     MPC_HIP(ctx, hipSetDevice(ctx->device));
     const mpck::SolveWorkspace W = mpck::carve_solve_workspace(ws, ctx->horizon, rows);
-    MPC_HIP(ctx, mpck::launch_solve_result(ctx->horizon, W, count, x, fun, nit, status, stats, static_cast<hipStream_t>(stream)));
+    MPC_HIP(ctx, mpck::launch_solve_result(ctx->horizon, W, count, ctx->solve_slot, x, fun, nit, status, stats,
+                                           static_cast<hipStream_t>(stream)));
     return MPC_OK;
 }
 

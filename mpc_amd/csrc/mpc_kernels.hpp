@@ -84,15 +84,15 @@ struct SolveWorkspace {
     double *lb, *ub;
     double *X, *XE, *X0, *S, *LO, *HI, *MU, *RM, *F, *C, *G, *NZ, *L, *V, *ACC;
     ::slsqp_state *ST;
-    int32_t *MODE, *ITER, *QPMODE, *QPFLAGS, *DONE, *LIST_F, *LIST_G, *LIST_Q, *counters;
+    int32_t *MODE, *ITER, *QPMODE, *QPFLAGS, *LIST_F[2], *LIST_G[2], *LIST_Q[2], *counters;   // lists, counters: two slots
 };
 SolveWorkspace carve_solve_workspace(void *base, int H, int rows);
 size_t solve_workspace_bytes(int H, int rows);
 hipError_t launch_solve_begin(const mpc_params &P, const SolveWorkspace &W, int count, const double *x0, double acc, int maxiter,
                               hipStream_t stream);
-hipError_t launch_solve_body(int H, const SolveWorkspace &W, int count, hipStream_t stream);
-hipError_t launch_solve_result(int H, const SolveWorkspace &W, int count, double *x, double *fun, int32_t *nit, int32_t *status,
-                               int32_t *stats, hipStream_t stream);
+hipError_t launch_solve_body(int H, const SolveWorkspace &W, int bound, int old_slot, hipStream_t stream);
+hipError_t launch_solve_result(int H, const SolveWorkspace &W, int count, int slot, double *x, double *fun, int32_t *nit,
+                               int32_t *status, int32_t *stats, hipStream_t stream);
 hipError_t launch_copy_i32(const int32_t *src, int32_t *dst, hipStream_t stream);
 // One request list of a device-resident solve: evaluate rows list[0 .. *count) of the per-problem arrays in place
 // (x from XE, outputs to the problem's own rows).  `bound` >= *count sizes the grid; surplus workgroups exit.
@@ -100,6 +100,7 @@ struct RowList {
     const int32_t *list = nullptr;    // device, row numbers
     const int32_t *count = nullptr;   // device, how many
     int bound = 0;
+    int32_t *head = nullptr;          // device, zero on entry: work-queue head of the QP kernel (teams take requests in turn)
 };
 hipError_t launch_prefix_rows(const mpc_params &P, const double *decay, const mpc_scenarios &sc, const double *x, double *cost,
                               double *grad, double *con, double *nz, const RowList &rows, hipStream_t stream);

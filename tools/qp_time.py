@@ -9,7 +9,8 @@ from mpc_amd.native_solver import NativeBatch
 from mpc_amd.slsqp_state import nz_scatter_index
 
 H, N = 20, 6
-K = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+K = int(sys.argv[1]) if len(sys.argv) > 1 and not sys.argv[1].startswith("-") else 4096
+FIRST_ONLY = "--first" in sys.argv      # only the first QP of every solve (identity Hessian, many active bounds)
 lib = native_solver.load()
 mp = params_for(H)
 co, hs = host_scenarios(mp, N, motion="angular", cfg_id=3, goal_jitter=0.0)
@@ -37,6 +38,8 @@ while True:
     if len(wg):
         _, g, _, a = co.eval_fd(rows(wg, np.clip(b.X[wg], lb, ub))); b.G[wg, :n] = g; b.NZ[wg] = a.reshape(len(wg), -1)[:, scatter]
 lib.mpc_slsqp_set_lsq(None)
+if FIRST_ONLY:
+    rec = [r for r in rec if np.count_nonzero(r[0][:-1]) == n]
 print(f"{len(rec)} QPs recorded; host core {1e3 * t_host[0] / len(rec):.3f} ms per QP (1 thread)", flush=True)
 ctx = MpcContext(mp, K, 0)
 reps = (K + len(rec) - 1) // len(rec)
