@@ -249,16 +249,22 @@ def single_tick_latency(device, with_cpu):
     return out
 
 
-def solve_rate(ctx, mp, sample, threads, rank, world, dist, device_qp=True):
+def solve_rate(ctx, mp, sample, threads, rank, world, dist, driver="resident"):
     """MPC solves/s on a bounded sample (BASELINE.json's second metric): full SLSQP solves of
-    angular-motion scenarios (configs[2] shape), one tick each.  device_qp: evaluations, the BFGS update and
-    the quadratic subproblem of every major iteration run on the GPU (mpc_qp_step), the O(n + m) logic of
-    the method in libmpc_slsqp.so on `threads` host threads per GPU (DeviceQpSLSQP).  Otherwise the whole
-    SLSQP core runs on the host threads (NativeBatchedSLSQP) and only the evaluations on the GPU: that rate
-    is host-bound.  Iterates are bit-identical either way.  Every rank calls this; a rank that fails
-    reports it and all ranks skip together (no hang)."""
+    angular-motion scenarios (configs[2] shape), one tick each.  Drivers (identical iterates, bit for bit):
+      resident   everything on the GPU (mpc_solve_*): evaluations, BFGS update + QP, and Kraft's O(n + m) body as
+                 a kernel over device-side request lists; one host thread enqueues rounds (ResidentSLSQP);
+      device_qp  evaluations and BFGS update + QP on the GPU (mpc_qp_step), the body in libmpc_slsqp.so on `threads`
+                 host threads per GPU (DeviceQpSLSQP);
+      native     the whole SLSQP core on the host threads (NativeBatchedSLSQP), evaluations on the GPU: host-bound.
+    Every rank calls this; a rank that fails reports it and all ranks skip together (no hang)."""
+    from mpc_amd.device_solver import ResidentSLSQP
     from mpc_amd.native_solver import DeviceQpSLSQP, NativeBatchedSLSQP
     from mpc_amd.solver import BatchedMPC
+
+    device_qp = driver != "native"
+    if driver == "resident":
+        threads = 1
 
     def all_ok(ok):
         if dist is None:
@@ -272,9 +278,12 @@ def solve_rate(ctx, mp, sample, threads, rank, world, dist, device_qp=True):
     try:
         hs = make_scenarios(mp, DeviceKinematics(ctx), count, motion="angular", cfg_id=3, goal_jitter=0.0,
                             first=rank * count)
-        native = (DeviceQpSLSQP if device_qp else NativeBatchedSLSQP)(ctx, threads=threads, capacity=count)
+        if driver == "resident":
+            native = ResidentSLSQP(ctx, capacity=count, lanes=1)
+        else:
+            native = (DeviceQpSLSQP if driver == "device_qp" else NativeBatchedSLSQP)(ctx, threads=threads, capacity=count)
         log("solver up")
-        warm = min(count, 2 * threads)
+        warm = min(count, 32)
         BatchedMPC(ctx, solver=native).compute_control(hs.q0[:warm], hs.state0[:warm, 12:18], hs.target[:warm], hs.base[:warm])
         torch.cuda.synchronize()
     except Exception as exc:  # noqa: BLE001 - the evals/s line must survive a host-side problem
@@ -305,13 +314,16 @@ def solve_rate(ctx, mp, sample, threads, rank, world, dist, device_qp=True):
         all_reduce(dist, stats, dist.ReduceOp.SUM)
         stats[0] = mx[0]
     dt_all, solved, conv, nfd, nf = (float(v) for v in stats.tolist())
-    where = ("BFGS updates and QP subproblems on the GPU (mpc_qp_step), SLSQP's scalar logic" if device_qp
-             else "SLSQP cores")
-    out = {"value": solved / dt_all, "unit": "solves/s", "driver": "DeviceQpSLSQP" if device_qp else "NativeBatchedSLSQP",
+    where = {"resident": "whole solves resident on the GPU (mpc_solve_*: Kraft's body, BFGS updates and QP subproblems "
+                         "as kernels over device-side request lists), one host thread per GPU enqueuing rounds",
+             "device_qp": f"BFGS updates and QP subproblems on the GPU (mpc_qp_step), SLSQP's scalar logic (libmpc_slsqp.so) "
+                          f"on {threads} host threads per GPU",
+             "native": f"SLSQP cores (libmpc_slsqp.so) on {threads} host threads per GPU"}[driver]
+    out = {"value": solved / dt_all, "unit": "solves/s",
+           "driver": {"resident": "ResidentSLSQP", "device_qp": "DeviceQpSLSQP", "native": "NativeBatchedSLSQP"}[driver],
            "host_bound": not device_qp, "host_threads_per_gpu": threads,
            "sample": f"{int(solved)} angular-motion scenarios ({count} per GPU), H={mp.horizon}, one tick each, "
-                     f"{int(conv)} converged, {int(nfd)} eval_fd + {int(nf)} eval scenario-evals on the GPU, {where} "
-                     f"(libmpc_slsqp.so) on {threads} host threads per GPU",
+                     f"{int(conv)} converged, {int(nfd)} eval_fd + {int(nf)} eval scenario-evals on the GPU, {where}",
            "seconds": dt_all, "mean_iterations": float(r.nit.mean()), "rounds_rank0": r.rounds,
            "rank0_core_seconds_busiest_thread": r.t_core, "rank0_seconds_serving_from_gpu": r.t_serve}
     out["gathered"] = {"rows": int(table.shape[0]), "columns": "f*, u0[6], nit, status",
@@ -476,13 +488,13 @@ def main():
     if gathered is not None:
         assert torch.equal(gathered[rank * S:(rank + 1) * S], out.cost)
 
-    solves = None
+    solves, workers = None, 1
     if not args.only_main and args.solve_sample > 0:        # every rank takes part: one pool per GPU
         from mpc_amd.pool import host_core_budget
 
         local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
         workers = args.solve_workers or max(1, min(15, host_core_budget(local_world) - 1))
-        log(f"solves leg: {workers} host threads")
+        log(f"solves leg (host threads for the comparison drivers: {workers})")
         solves = solve_rate(ctx, mp, args.solve_sample, workers, rank, world, dist)
         log("solves leg done")
 
@@ -558,13 +570,21 @@ def main():
         if solves is not None:
             line["solves"] = solves
             if extras and world == 1 and "error" not in solves:
+                try:        # 4,096 scenarios (configs[1]'s batch size) through the same driver: latency-bound rounds
+                    line["solves_4096_scenarios"] = solve_rate(ctx, mp, 4096, 1, 0, 1, None)
+                except Exception as exc:  # noqa: BLE001 - a comparison figure, not the metric
+                    line["solves_4096_scenarios"] = {"error": repr(exc)}
+                try:        # SLSQP's scalar logic on host threads, QP on the GPU: last round's default driver
+                    line["solves_device_qp_host_logic"] = solve_rate(ctx, mp, args.solve_sample, workers, 0, 1, None,
+                                                                     driver="device_qp")
+                except Exception as exc:  # noqa: BLE001 - a comparison figure, not the metric
+                    line["solves_device_qp_host_logic"] = {"error": repr(exc)}
                 try:        # the host-only driver on a smaller sample: what the GPU-side QP buys
-                    line["solves_host_core"] = solve_rate(ctx, mp, 256 * solves["host_threads_per_gpu"],
-                                                          solves["host_threads_per_gpu"], 0, 1, None, device_qp=False)
+                    line["solves_host_core"] = solve_rate(ctx, mp, 256 * workers, workers, 0, 1, None, driver="native")
                 except Exception as exc:  # noqa: BLE001 - a comparison figure, not the metric
                     line["solves_host_core"] = {"error": repr(exc)}
                 try:
-                    line["solves_scipy_core_pool"] = pool_solve_rate(ctx, mp, 32, solves["host_threads_per_gpu"])
+                    line["solves_scipy_core_pool"] = pool_solve_rate(ctx, mp, 32, workers)
                 except Exception as exc:  # noqa: BLE001 - a comparison figure, not the metric
                     line["solves_scipy_core_pool"] = {"error": repr(exc)}
         if extras and world == 1:

@@ -111,6 +111,7 @@ qp_step_kernel(int H, int count, int rows, const int32_t *__restrict__ index, co
         double *l = L + p * ldl, *r = R + p * mg, *v = V + p * n;
         const double *g = G + p * n, *c = C + p * m, *nz = NZ + p * nzc;
         const int fl = flags[q];
+        QP_MARK_START(T);
         if (fl & 1) {                                            // the factor of the identity
             PAR_FOR(T, e, 0, ldl - 1) W.E[e] = 0.0;
             T.sync();
@@ -124,11 +125,14 @@ qp_step_kernel(int H, int count, int rows, const int32_t *__restrict__ index, co
                 W.zz[i] = s_in[q * n + i];
             }
             T.sync();
+            QP_MARK(T, 8);    // staging in
             lsqspmd::bfgs_update(T, W, H, W.E, g, nz, r, W.bb, W.zz, W.xs);
+            QP_MARK(T, 9);    // BFGS update
         }
         T.sync();
         if (fl & 3) PAR_FOR(T, e, 0, ldl - 1) l[e] = W.E[e];
         T.sync();
+        QP_MARK(T, 10);       // staging in (no update) / factor written back
         const int md = lsqspmd::lsq(T, W, H, g, c, nz, lo + q * n, hi + q * n, s_out + q * n, r);
         T.sync();
         if (md == 1) {
@@ -139,8 +143,24 @@ qp_step_kernel(int H, int count, int rows, const int32_t *__restrict__ index, co
         }
         if (threadIdx.x == 0) mode[q] = md;
         __syncthreads();
+        QP_MARK_START(T);
+        QP_MARK(T, 11);       // (nothing: calibration of the mark itself)
     }
 }
+
+#if defined(MPC_QP_PROFILE)
+}  // namespace
+extern "C" int mpc_debug_qp_profile(unsigned long long *out32, int reset)
+{
+    hipError_t e = hipMemcpyFromSymbol(out32, HIP_SYMBOL(mpc_qp_prof), 32 * sizeof(unsigned long long));
+    if (e == hipSuccess && reset) {
+        unsigned long long z[32] = {0};
+        e = hipMemcpyToSymbol(HIP_SYMBOL(mpc_qp_prof), z, sizeof(z));
+    }
+    return e == hipSuccess ? 0 : -2;
+}
+namespace {
+#endif
 
 // LDS of one team, in bytes, when its small pool goes there (0: it stays in global memory).
 size_t lds_bytes(int H)

@@ -20,6 +20,7 @@
 #include <math.h>
 
 #if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
 #define SPMD_HD __host__ __device__
 #else
 #define SPMD_HD
@@ -29,6 +30,30 @@
 #define SPMD_UNROLL _Pragma("unroll")
 #else
 #define SPMD_UNROLL
+#endif
+
+// Development only (-DMPC_QP_PROFILE, never in the shipped library): thread 0 of every team adds the shader cycles
+// between two marks to a per-phase counter.
+#if defined(MPC_QP_PROFILE) && defined(__HIPCC__)
+__device__ unsigned long long mpc_qp_prof[32];
+#endif
+#if defined(MPC_QP_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
+#define QP_MARK(T, id)                                                                       \
+    do {                                                                                     \
+        (T).sync();                                                                          \
+        if ((T).tid() == 0) {                                                                \
+            const unsigned long long now_ = __builtin_readcyclecounter();                    \
+            atomicAdd(&mpc_qp_prof[id], now_ - *reinterpret_cast<unsigned long long *>(&W.sc[15])); \
+            *reinterpret_cast<unsigned long long *>(&W.sc[15]) = now_;                       \
+        }                                                                                    \
+    } while (0)
+#define QP_MARK_START(T)                                                                     \
+    do {                                                                                     \
+        if ((T).tid() == 0) *reinterpret_cast<unsigned long long *>(&W.sc[15]) = __builtin_readcyclecounter(); \
+    } while (0)
+#else
+#define QP_MARK(T, id) do {} while (0)
+#define QP_MARK_START(T) do {} while (0)
 #endif
 
 namespace lsqspmd {
@@ -176,6 +201,7 @@ SPMD_HD int nnls(const Team &T, const Work &W, int mrow, int ncol, int mg, doubl
             w[j - 1] = s;
         }
         T.sync();
+        QP_MARK(T, 16);   // NNLS: dual pass
         int accepted = 0, j = 0, iz = 0;
         double up = 0.0;
         for (;;) {
@@ -266,6 +292,7 @@ SPMD_HD int nnls(const Team &T, const Work &W, int mrow, int ncol, int mg, doubl
             T.sync();
             if (W.isc[1]) { accepted = 1; up = W.sc[1]; break; }
         }
+        QP_MARK(T, 17);   // NNLS: candidate search and test
         if (accepted < 0) break;
         // ---- step five: column j enters the set
         PAR_FOR(T, r, 0, m) b[r] = z[r];                   // W.piv already holds the column with its new pivot
@@ -316,6 +343,7 @@ SPMD_HD int nnls(const Team &T, const Work &W, int mrow, int ncol, int mg, doubl
         PAR_FOR(T, r, npp1, m + 1) AT(r, j) = 0.0;         // rows npp1..m of the new column
         if (T.tid() == 0) w[j - 1] = 0.0;
         T.sync();
+        QP_MARK(T, 18);   // NNLS: Householder application
         // ---- steps six to eleven: solve, step length, possibly drop columns.  The arithmetic is the serial text's,
         //      entry for entry; what runs in parallel are the entries that do not depend on each other: the rows of one
         //      elimination step of the triangular solve (on the team's first wavefront, whose LDS traffic needs no
@@ -464,6 +492,7 @@ SPMD_HD int nnls(const Team &T, const Work &W, int mrow, int ncol, int mg, doubl
             PAR_FOR(T, r, 0, m) z[r] = b[r];
             T.sync();
         }
+        QP_MARK(T, 19);   // NNLS: steps six to eleven
         if (failed) { mode = 3; break; }
     }
     // ---- L280
@@ -516,9 +545,23 @@ SPMD_HD inline RowDesc describe_row(int H, int i, const double *cvals, const dou
     return d;
 }
 
-template <int NB, int R>
+#if defined(__HIP_DEVICE_COMPILE__)
+// the double that lane `lane` of this wavefront holds in v, for every lane, through the scalar unit (two v_readlane):
+// how a wavefront shares entries of the triangle that it loaded one per lane, instead of every lane reading every entry
+// from LDS itself (64 lanes reading one address still cost the LDS pipe 64 lanes' worth of bandwidth)
+__device__ __forceinline__ double lane_bcast(double v, int lane)
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
+#endif
+
+// COOP: every lane of the wavefront is here together (device only; the caller guarantees it), so the rows of e are
+// loaded cooperatively, one entry per lane, and broadcast with lane_bcast.  kb_lo <= every lane's first_any.
+template <int NB, int R, bool COOP>
 SPMD_HD inline void transform_cols(const Work &W, int n, int mg, int H, const double *nz, double *const *dst, int jj0,
-                                   const RowDesc *d, int first_any, double *th)
+                                   const RowDesc *d, int first_any, double *th, int kb_lo = 0, bool store = true)
 {
     constexpr int NC = 6 * NB;
     const int jb = 6 * jj0;
@@ -529,6 +572,54 @@ SPMD_HD inline void transform_cols(const Work &W, int n, int mg, int H, const do
         SPMD_UNROLL
         for (int c = 0; c < NC; ++c) acc[r][c] = 0.0;
     }
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (COOP) {
+        // entry number t of the 6 x NC block of e that six steps k = 6 kb + q need is e(6 kb + t / NC, jb + t % NC):
+        // lane L holds entries L and L + 64
+        static_assert(6 * NC <= 128, "two entries per lane cover the block");
+        const int lane = (int)(threadIdx.x & 63u);
+        const int qa = lane / NC, ca = lane - qa * NC;
+        const int tb = lane + 64, qb = tb / NC, cb = tb - qb * NC;
+        const bool has_a = lane < 6 * NC, has_b = tb < 6 * NC;
+        for (int kb = kb_lo; kb < jj0; ++kb) {
+            const int ka = 6 * kb + qa, kbb = 6 * kb + qb;
+            const double va = has_a ? W.E[EO(ka) + (jb - ka) + ca] : 0.0;
+            const double vb = has_b ? W.E[EO(kbb) + (jb - kbb) + cb] : 0.0;
+            if (kb >= first_any) {
+                double gk[R][6];
+                SPMD_UNROLL
+                for (int r = 0; r < R; ++r) {
+                    SPMD_UNROLL
+                    for (int q = 0; q < 6; ++q) gk[r][q] = dst[r][(size_t)(6 * kb + q) * mg];
+                }
+                // products first, six columns at a time, then the additions: an addition right behind its own product
+                // would wait out the multiplier's latency every time
+                SPMD_UNROLL
+                for (int q = 0; q < 6; ++q) {
+                    SPMD_UNROLL
+                    for (int c6 = 0; c6 < NC; c6 += 6) {
+                        double pr[R][6];
+                        SPMD_UNROLL
+                        for (int c = 0; c < 6; ++c) {
+                            const int t = q * NC + c6 + c;
+                            const double e = t < 64 ? lane_bcast(va, t) : lane_bcast(vb, t - 64);
+                            SPMD_UNROLL
+                            for (int r = 0; r < R; ++r) pr[r][c] = gk[r][q] * e;
+                        }
+#if defined(__HIP_DEVICE_COMPILE__)
+                        __builtin_amdgcn_sched_barrier(0);
+#endif
+                        SPMD_UNROLL
+                        for (int c = 0; c < 6; ++c) {
+                            SPMD_UNROLL
+                            for (int r = 0; r < R; ++r) acc[r][c6 + c] = acc[r][c6 + c] + pr[r][c];
+                        }
+                    }
+                }
+            }
+        }
+    } else
+#endif
     {
         const double *er = W.E + jb;                       // er[c] = e(k, jb + c), advanced row by row
         for (int kb = 0; kb < jj0; ++kb) {
@@ -588,16 +679,16 @@ SPMD_HD inline void transform_cols(const Work &W, int n, int mg, int H, const do
             const double orig = (c % 6 == d[r].a) ? val[r][c / 6] : 0.0;
             const double gn = (orig - t[r]) / diag;
             acc[r][c] = gn;
-            dst[r][(size_t)(jb + c) * mg] = gn;
+            if (store) dst[r][(size_t)(jb + c) * mg] = gn;
             th[r] = th[r] + gn * fj;
         }
     }
 #undef EO
 }
 
-template <int R>
+template <int R, bool COOP = false>
 SPMD_HD inline void transform_rows(const Work &W, int H, const int *rows, const double *cvals, const double *nz,
-                                   const double *lo, const double *hi, double *const *dst)
+                                   const double *lo, const double *hi, double *const *dst, bool store = true)
 {
     const int n = 6 * H, mg = 12 * (H + 1) + 2 * n;
     RowDesc d[R];
@@ -609,22 +700,36 @@ SPMD_HD inline void transform_rows(const Work &W, int H, const int *rows, const 
         th[r] = 0.0;
         first_any = d[r].first < first_any ? d[r].first : first_any;
     }
+    int skip_to = first_any;           // blocks before it are zeros for every row handled here
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (COOP) {              // ... for every row of the WAVEFRONT: its lanes walk the blocks together
+        SPMD_UNROLL
+        for (int off = 32; off > 0; off >>= 1) {
+            const int other = __shfl_xor(skip_to, off);
+            skip_to = other < skip_to ? other : skip_to;
+        }
+    }
+#endif
     int jj = 0;
     for (; jj + MPC_QP_NB <= H; jj += MPC_QP_NB) {
-        if (jj + MPC_QP_NB <= first_any) {                  // all zeros so far: (0 - 0) / e(j, j)
+        if (jj + MPC_QP_NB <= skip_to) {                    // all zeros so far: (0 - 0) / e(j, j)
             for (int c = 0; c < 6 * MPC_QP_NB; ++c) {
                 const int j = 6 * jj + c;
                 const double res = (0.0 - 0.0) / W.E[j * n - (j * (j - 1)) / 2];
-                SPMD_UNROLL
-                for (int r = 0; r < R; ++r) dst[r][(size_t)j * mg] = res;
+                if (store) {
+                    SPMD_UNROLL
+                    for (int r = 0; r < R; ++r) dst[r][(size_t)j * mg] = res;
+                }
             }
         } else {
-            transform_cols<MPC_QP_NB, R>(W, n, mg, H, nz, dst, jj, d, first_any, th);
+            transform_cols<MPC_QP_NB, R, COOP>(W, n, mg, H, nz, dst, jj, d, first_any, th, skip_to, store);
         }
     }
-    for (; jj < H; ++jj) transform_cols<1, R>(W, n, mg, H, nz, dst, jj, d, first_any, th);
-    SPMD_UNROLL
-    for (int r = 0; r < R; ++r) dst[r][(size_t)n * mg] = d[r].hval - th[r];
+    for (; jj < H; ++jj) transform_cols<1, R, COOP>(W, n, mg, H, nz, dst, jj, d, first_any, th, skip_to < jj ? skip_to : jj, store);
+    if (store) {
+        SPMD_UNROLL
+        for (int r = 0; r < R; ++r) dst[r][(size_t)n * mg] = d[r].hval - th[r];
+    }
 }
 
 // Kraft's LSQ for the MPC shape.  W.E holds the packed LDL' factor l on entry ((n+1)n/2 + 1 entries; it is
@@ -644,6 +749,7 @@ SPMD_HD int lsq(const Team &T, const Work &W, int H, const double *g, const doub
 {
     const int n = 6 * H, m = 12 * (H + 1), mg = m + 2 * n;
 #define EO(r) ((r) * n - ((r) * ((r) - 1)) / 2)
+    QP_MARK_START(T);
     // ---- e = sqrt(d) l^T in place (row r of e is column r of l scaled by sqrt(d_r))
     PAR_FOR(T, i, 0, n) {
         W.piv[i] = sqrt(W.E[EO(i)]);
@@ -659,6 +765,7 @@ SPMD_HD int lsq(const Team &T, const Work &W, int H, const double *g, const doub
         for (int c = 1; c < n - r; ++c) er[c] = d * er[c];
     }
     T.sync();
+    QP_MARK(T, 0);   // e in place
     // ---- f: solve e^T f = g by forward substitution, column-oriented: once f(k) is known every later row adds its
     //      term e(k, i) f(k), which it does in the order k = 0, 1, ... of the serial dot product; the thread that
     //      owns row k + 1 (always thread 0) finishes f(k + 1) in the same sweep.  Then negate.
@@ -676,6 +783,7 @@ SPMD_HD int lsq(const Team &T, const Work &W, int H, const double *g, const doub
     }
     PAR_FOR(T, i, 0, n) W.ff[i] = -1.0 * W.ff[i];
     T.sync();
+    QP_MARK(T, 1);   // forward substitution
     // ---- LSI: "QR" of the triangular e (pivot arithmetic only, see slsqp_core.c) applied to f: a row touches
     //      nothing but itself, one row per index
     PAR_FOR(T, i, 0, n - 1) {
@@ -709,19 +817,29 @@ SPMD_HD int lsq(const Team &T, const Work &W, int H, const double *g, const doub
         if (!(fabs(W.E[EO(j)]) >= 2.22e-16)) W.isc[8] = 0;
     T.sync();
     if (!W.isc[8]) return 5;
+    QP_MARK(T, 2);   // QR rows
     // ---- [g h] <- [g e^-1, h - g f], one row per index, into the matrix NNLS works on
     //      (MPC_QP_ROWS rows per index, spread evenly over the matrix: they share the reads of e; m + 2n = 12(2H + 1)
     //      is a multiple of 2, 3 and 4)
-    PAR_FOR(T, i, 0, mg / MPC_QP_ROWS) {
-        int rows[MPC_QP_ROWS];
-        double *dst[MPC_QP_ROWS];
-        SPMD_UNROLL
-        for (int r = 0; r < MPC_QP_ROWS; ++r) {
-            rows[r] = i + r * (mg / MPC_QP_ROWS);
-            dst[r] = W.AT + rows[r];
+    //      Whole wavefronts walk the loop together (a lane beyond the last row repeats that row without storing), so
+    //      that on the device a wavefront can load the rows of e once for all its lanes.
+    {
+        const int per = mg / MPC_QP_ROWS, width = T.size() < 64 ? T.size() : 64;
+        for (int base = (T.tid() / width) * width; base < per; base += T.size()) {
+            const int want = base + T.tid() % width;
+            const bool mine = want < per;
+            const int i = mine ? want : per - 1;
+            int rows[MPC_QP_ROWS];
+            double *dst[MPC_QP_ROWS];
+            SPMD_UNROLL
+            for (int r = 0; r < MPC_QP_ROWS; ++r) {
+                rows[r] = i + r * (mg / MPC_QP_ROWS);
+                dst[r] = W.AT + rows[r];
+            }
+            transform_rows<MPC_QP_ROWS, true>(W, H, rows, cvals, nz, lo, hi, dst, mine);
         }
-        transform_rows<MPC_QP_ROWS>(W, H, rows, cvals, nz, lo, hi, dst);
     }
+    QP_MARK(T, 3);   // transform
     // ---- LDP: NNLS on the copy of [g h]^T with right-hand side e_{n+1}
     PAR_FOR(T, i, 0, n) W.bb[i] = 0.0;
     if (T.tid() == 0) W.bb[n] = 1.0;
@@ -732,6 +850,7 @@ SPMD_HD int lsq(const Team &T, const Work &W, int H, const double *g, const doub
     rnorm = W.sc[2];
     if (mode != 1) return mode;
     if (rnorm <= 0.0) return 4;
+    QP_MARK(T, 4);   // NNLS
     // ---- the rows of the transformed [g h] that are in the final set (NNLS overwrote its copy): computed again
     PAR_FOR(T, i, 0, mg)
         if (W.xn[i] != 0.0) {
@@ -740,6 +859,7 @@ SPMD_HD int lsq(const Team &T, const Work &W, int H, const double *g, const doub
             transform_rows<1>(W, H, rows, cvals, nz, lo, hi, dst);
         }
     T.sync();
+    QP_MARK(T, 5);   // final-set rows
     // ---- column sums against the NNLS solution (column n is h): only the rows in the final set contribute, in
     //      ascending order as in the serial sums over all rows (every other entry of the solution is an exact zero)
     const int nset = W.isc[11];
@@ -775,6 +895,7 @@ SPMD_HD int lsq(const Team &T, const Work &W, int H, const double *g, const doub
     PAR_FOR(T, j, 0, n) W.xs[j] = fac * W.zz[j];
     PAR_FOR(T, i, 0, mg) y[i] = 0.0 + fac * W.xn[i];
     T.sync();
+    QP_MARK(T, 6);   // column sums
     // ---- back to the original variables: x = e^-1 (x + f) by back substitution, then the box.  Row i's sum runs
     //      over j = i + 1, i + 2, ... while x(j) becomes known in the opposite order, so the sum itself is a serial
     //      chain (thread 0); the products are formed by the team first.
@@ -807,6 +928,7 @@ SPMD_HD int lsq(const Team &T, const Work &W, int H, const double *g, const doub
         s[i] = v;
     }
     T.sync();
+    QP_MARK(T, 7);   // back substitution + box
     return 1;
 #undef EO
 }
@@ -861,6 +983,7 @@ SPMD_HD void ldl(const Team &T, const Work &W, int n, double *a, double *z, doub
             ij = ij + (n - i) + 1;
         }
     }
+    QP_MARK(T, 20);   // ldl A
     // ---- B
     double t0 = 1.0 / sigma;
     if (sigma <= 0.0) {
@@ -903,6 +1026,7 @@ SPMD_HD void ldl(const Team &T, const Work &W, int n, double *a, double *z, doub
         gam[i] = t / tp;
     }
     T.sync();
+    QP_MARK(T, 21);   // ldl B
     // ---- C
     PAR_FOR(T, j, 1, n) {
         double zj = z[j];
@@ -980,8 +1104,11 @@ SPMD_HD void bfgs_update(const Team &T, const Work &W, int H, double *l, const d
         }
         T.sync();
     }
+    QP_MARK(T, 12);   // BFGS products and damping
     ldl(T, W, n, l, u, +1.0 / h1, v);
+    QP_MARK(T, 13);   // first rank-one update
     ldl(T, W, n, l, v, -1.0 / h2, u);
+    QP_MARK(T, 14);   // second rank-one update
 }
 
 }  // namespace lsqspmd
