@@ -246,6 +246,29 @@ def single_tick_latency(device, with_cpu):
             ref.compute_control(*dicts(i))
             cpu.append(time.perf_counter() - t0)
         out["cpu_numpy_ms_per_tick"] = 1e3 * float(np.median(cpu))
+    # the same single tick at the benchmark horizon (H=20): scipy's own SLSQP core on the host, callbacks on the device
+    mp20 = MpcParams.reference_yaml_defaults(horizon=20)
+    m20 = GpuURMPC(mp20, device=device)
+    hs20 = make_scenarios(mp20, DeviceKinematics(m20._ctx), 6, motion="linear", cfg_id=1)
+    rows20 = [i for i in range(6) if hs20.active[i]][:4]
+
+    def dicts20(i):
+        return ({"position": hs20.q0[i], "velocity": np.zeros(6)},
+                {"position": hs20.state0[i, 12:15], "orientation": hs20.state0[i, 15:18]},
+                {"position": hs20.target[i, :3], "orientation": hs20.target[i, 3:]},
+                {"position": hs20.base[i, 0:3], "orientation": hs20.base[i, 3:6], "linear_velocity": hs20.base[i, 6:9],
+                 "angular_velocity": hs20.base[i, 9:12]})
+
+    m20.compute_control(*dicts20(rows20[0]))
+    t20 = []
+    for i in rows20:
+        one = GpuURMPC(mp20, device=device)
+        t0 = time.perf_counter()
+        one.compute_control(*dicts20(i))
+        t20.append(time.perf_counter() - t0)
+    out["H20_ms_per_tick"] = 1e3 * float(np.median(t20))
+    out["H20_note"] = ("same drop-in class at H=20 (scipy's compiled SLSQP core on one host core, every callback served by "
+                       "the device); the numpy path's H=20 tick is cpu_baseline.solves_value (about 4 s)")
     return out
 
 

@@ -174,7 +174,8 @@ int mpc_predict_base_dynamic(mpc_ctx *ctx, int count, const double *base, const 
  *   Jc[s]        = J(q[s])                                                                (MPC:157)
  *   u_init[s]    = J^T (J J^T + 0.01 I)^-1 twist, the damped least-squares start          (MPC:112-143,168-175)
  *   x0[s]        = previous solution shifted by one step with u_init appended where has_solution[s],
- *                  else u_init repeated H times (MPC:177-185); x0 / prev_solution / has_solution may be NULL.
+ *                  else u_init repeated H times (MPC:177-185); x0 / prev_solution / has_solution may be NULL;
+ *                  x0 must not overlap prev_solution (no in-place shift: MPC_ERR_INVALID_ARG).
  * q [N][6], ee_pose [N][6] = [pos, rpy], base [N][12], dyn_host as in mpc_predict_base_dynamic.
  * The 6x6 solve is Gaussian elimination with partial pivoting in fp64; it agrees with LAPACK's to
  * rounding, not bit for bit. */

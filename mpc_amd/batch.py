@@ -290,11 +290,13 @@ class MpcContext:
         return dst
 
     # ---- the steps either side of it -------------------------------------------------------
-    def jacobian(self, q: torch.Tensor) -> torch.Tensor:
-        """Batched ``get_jacobian`` (ur20_dynamics.py:74-87): q [N,6] -> J [N,6,6]."""
+    def jacobian(self, q: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Batched ``get_jacobian`` (ur20_dynamics.py:74-87): q [N,6] -> J [N,6,6] (``out``: any [N,36]-sized buffer)."""
         N = int(q.shape[0])
         qp = self._chk(q, (N, 6), "q")
-        J = self._new(N, 6, 6)
+        J = self._new(N, 6, 6) if out is None else out
+        if out is not None:
+            self._chk(out.view(N, 36), (N, 36), "J")
         _ffi.check(self._ctx, self._lib.mpc_jacobian(self._ctx, N, qp, J.data_ptr(), self._stream()))
         return J
 
@@ -306,11 +308,14 @@ class MpcContext:
         _ffi.check(self._ctx, self._lib.mpc_fk(self._ctx, N, qp, pose.data_ptr(), self._stream()))
         return pose
 
-    def predict_base_dynamic(self, base: torch.Tensor) -> torch.Tensor:
+    def predict_base_dynamic(self, base: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         """Batched ``_predict_base_dynamic`` (ur_mpc.py:606-651): base [N,12] -> [N,H,12]."""
         N = int(base.shape[0])
         bp = self._chk(base, (N, 12), "base")
-        out = self._new(N, self.H, 12)
+        if out is None:
+            out = self._new(N, self.H, 12)
+        else:
+            self._chk(out, (N, self.H, 12), "base_traj")
         dyn = self.params.base_dyn_array()
         _ffi.check(self._ctx, self._lib.mpc_predict_base_dynamic(
             self._ctx, N, bp, dyn.ctypes.data_as(C.POINTER(C.c_double)), out.data_ptr(), self._stream()))

@@ -754,7 +754,8 @@ hipError_t launch_prefix(const mpc_params &P, const double *decay, const mpc_sce
         }
     }
     int used = 0;
-    for (int first = 0, i = 0; first < sc.count; first += chunk, ++i) {
+    hipError_t err = hipSuccess;
+    for (int first = 0, i = 0; first < sc.count && err == hipSuccess; first += chunk, ++i) {
         const int cnt = (sc.count - first < chunk) ? sc.count - first : chunk;
         const int h = piped ? (i & 1) : 0;
         PrefixArgs B = A;
@@ -768,32 +769,29 @@ hipError_t launch_prefix(const mpc_params &P, const double *decay, const mpc_sce
         if (B.con) B.con += (size_t)first * m;
         if (B.jac) B.jac += (size_t)first * n * m;
         B.compact = workspace + (size_t)h * half; B.cstride = (int)per;
-        hipError_t e = hipSuccess;
-        if (piped && i >= 2) e = hipStreamWaitEvent(stream, pipe->drained[h], 0);   // half h is free again
-        if (e != hipSuccess) return e;
-        e = launch_mode<kCompact, 512>(P, B, g, (unsigned)cnt, stream);
-        if (e != hipSuccess) return e;
-        if (jac != nullptr) {
-            hipStream_t xs = stream;
-            if (piped) {
-                e = hipEventRecord(pipe->filled[h], stream);
-                if (e == hipSuccess) e = hipStreamWaitEvent(pipe->aux, pipe->filled[h], 0);
-                if (e != hipSuccess) return e;
-                xs = pipe->aux;
-            }
-            hipLaunchKernelGGL(expand_kernel, dim3((unsigned)cnt * (unsigned)H), dim3(kExpandThreads), 0, xs, H, cnt,
-                               B.compact, (int)per, B.jac);
-            e = hipGetLastError();
-            if (e == hipSuccess && piped) e = hipEventRecord(pipe->drained[h], pipe->aux);
-            if (e != hipSuccess) return e;
-            if (used < h + 1) used = h + 1;
+        if (piped && i >= 2) err = hipStreamWaitEvent(stream, pipe->drained[h], 0);   // half h is free again
+        if (err == hipSuccess) err = launch_mode<kCompact, 512>(P, B, g, (unsigned)cnt, stream);
+        if (err != hipSuccess || jac == nullptr) continue;
+        hipStream_t xs = stream;
+        if (piped) {
+            err = hipEventRecord(pipe->filled[h], stream);
+            if (err == hipSuccess) err = hipStreamWaitEvent(pipe->aux, pipe->filled[h], 0);
+            if (err != hipSuccess) continue;
+            xs = pipe->aux;
         }
+        hipLaunchKernelGGL(expand_kernel, dim3((unsigned)cnt * (unsigned)H), dim3(kExpandThreads), 0, xs, H, cnt,
+                           B.compact, (int)per, B.jac);
+        err = hipGetLastError();
+        if (err == hipSuccess && piped) err = hipEventRecord(pipe->drained[h], pipe->aux);
+        if (err == hipSuccess && used < h + 1) used = h + 1;
     }
-    for (int h = 0; piped && h < used; ++h) {   // ordinary stream ordering for whatever the caller enqueues next
-        hipError_t e = hipStreamWaitEvent(stream, pipe->drained[h], 0);
-        if (e != hipSuccess) return e;
+    // ordinary stream ordering for whatever the caller enqueues next; also on the error path, so that `stream` never
+    // runs ahead of work already queued on the second stream
+    for (int h = 0; piped && h < used; ++h) {
+        const hipError_t e = hipStreamWaitEvent(stream, pipe->drained[h], 0);
+        if (err == hipSuccess) err = e;
     }
-    return hipSuccess;
+    return err;
 }
 
 }  // namespace mpck

@@ -143,8 +143,7 @@ int mpc_ctx_create(int device, int horizon, int max_scenarios, mpc_ctx **out)
     hipError_t e = hipSetDevice(device);
     if (e == hipSuccess) e = static_scratch_for(device, &ctx->d_static);   // set-up: once per device
     if (e == hipSuccess) e = hipMalloc(&ctx->d_decay, sizeof(double) * (size_t)horizon);
-    if (e == hipSuccess)
-        e = hipMalloc(&ctx->d_fvals, sizeof(double) * (size_t)max_scenarios * (size_t)(6 * horizon + 1));
+    // (the per-rollout costs of MPC_ALGO_ROLLOUT are allocated by mpc_set_params, and only if that kernel will run)
     if (e != hipSuccess) {
         int rc = hip_fail(nullptr, e, "mpc_ctx_create");
         mpc_ctx_destroy(ctx);
@@ -215,6 +214,14 @@ int mpc_set_params(mpc_ctx *ctx, const mpc_params *p, const double *decay_host, 
             MPC_HIP(ctx, hipEventCreateWithFlags(&ctx->pipe.filled[h], hipEventDisableTiming));
             MPC_HIP(ctx, hipEventCreateWithFlags(&ctx->pipe.drained[h], hipEventDisableTiming));
         }
+    }
+    // per-rollout costs between the two kernels of MPC_ALGO_ROLLOUT: only that algorithm reads them
+    const bool rollout = p->algo == MPC_ALGO_ROLLOUT || (p->algo == MPC_ALGO_AUTO && !mpck::prefix_supported(*p));
+    if (rollout && !ctx->d_fvals) {
+        MPC_HIP(ctx, hipMalloc(&ctx->d_fvals, sizeof(double) * (size_t)ctx->max_scenarios * (size_t)(6 * ctx->horizon + 1)));
+    } else if (!rollout && ctx->d_fvals) {
+        (void)hipFree(ctx->d_fvals);
+        ctx->d_fvals = nullptr;
     }
     ctx->params = *p;
     ctx->have_params = true;
@@ -379,6 +386,11 @@ int mpc_prepare_tick(mpc_ctx *ctx, int count, const double *q, const double *dq,
         return fail(ctx, MPC_ERR_INVALID_ARG, "q/ee_pose/base/state0/base_traj/Jc/u_init/active must be non-NULL");
     if ((prev_solution != nullptr) != (has_solution != nullptr))
         return fail(ctx, MPC_ERR_INVALID_ARG, "prev_solution and has_solution go together");
+    if (x0 && prev_solution) {     // x0[i] = prev_solution[i + 6]: an in-place shift would read entries already overwritten
+        const size_t len = (size_t)count * 6 * (size_t)ctx->horizon;
+        if (x0 < prev_solution + len && prev_solution < x0 + len)
+            return fail(ctx, MPC_ERR_INVALID_ARG, "x0 must not overlap prev_solution");
+    }
     double dyn[6];
     std::memcpy(dyn, dyn_host, sizeof(dyn));
     MPC_HIP(ctx, hipSetDevice(ctx->device));

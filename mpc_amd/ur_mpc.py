@@ -138,6 +138,81 @@ class GpuURMPC:
         self._cache = None
         self.last_result = None
         self._kin = KinematicBasePredictor()
+        self._make_staging()
+
+    # ---- one tick's buffers: allocated once, so that a tick moves one small pinned block each way ------------
+    def _make_staging(self):
+        """Device-resident scenario of THIS controller plus pinned staging: per tick one H2D of [q, platform
+        state], one D2H of Jc, one H2D of [state0, target, previous_control]; per scipy callback one H2D of x and
+        one D2H of [f, grad f, c, structured dc/dx] (the dense dc/dx is filled in on the host, as the batched
+        drivers do)."""
+        ctx, p = self._ctx, self.params
+        dev, n, m, H = ctx.device, p.n, p.m, p.horizon
+        z = lambda *shape: torch.zeros(shape, dtype=torch.float64, device=dev)
+        pin = lambda count: torch.zeros(count, dtype=torch.float64).pin_memory()
+        self._qb_h, self._qb_d = pin(18), z(18)                       # [q(6), platform state(12)]
+        self._jc_h = pin(36)
+        self._in_h, self._in_d = pin(30), z(30)                       # [state0(18), target(6), previous_control(6)]
+        self._x_h, self._x_d = pin(n), z(1, n)
+        self._flags = (torch.zeros(1, dtype=torch.uint8, device=dev), torch.ones(1, dtype=torch.uint8, device=dev))
+        self._bt_d, self._jc_d = z(1, H, 12), z(1, 36)
+        self._structured = ctx.nz_supported()
+        nj = ctx.nz_count if self._structured else n * m
+        self._out_h, self._out_d = pin(1 + n + m + nj), z(1 + n + m + nj)
+        o = self._out_d
+        self._views = (o[0:1], o[1:1 + n].view(1, n), o[1 + n:1 + n + m].view(1, m),
+                       o[1 + n + m:].view(1, nj) if self._structured else o[1 + n + m:].view(1, n, m))
+        if self._structured:
+            from .slsqp_state import nz_scatter_index
+
+            self._scatter = nz_scatter_index(H)
+        self._tick_sc = None
+
+    def _tick_scenario(self, current_state, target_ee_pose) -> ScenarioBatch:
+        """The resident scenario of this tick (base_traj and Jc were written by the device a moment ago)."""
+        has_prev = hasattr(self, "previous_control")
+        h = self._in_h.numpy()
+        h[0:18] = current_state
+        h[18:21], h[21:24] = target_ee_pose["position"], target_ee_pose["orientation"]
+        h[24:30] = self.previous_control if has_prev else 0.0
+        self._in_d.copy_(self._in_h, non_blocking=True)
+        d = self._in_d
+        self._tick_sc = ScenarioBatch(d[0:18].view(1, 18), d[18:24].view(1, 6), self._bt_d, self._jc_d, d[24:30].view(1, 6),
+                                      self._flags[1 if has_prev else 0])
+        self._tick_scc = self._ctx._scen_c(self._tick_sc)      # checked once per tick; the callbacks reuse the struct
+        return self._tick_sc
+
+    def _evaluate_tick(self, x: np.ndarray):
+        """_evaluate on the resident scenario: one small copy each way per distinct x."""
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        key = ("tick", x.tobytes())
+        if key != self._cache_key:
+            if not np.all(np.isfinite(x)):
+                raise ValueError("non-finite control sequence")
+            ctx, p = self._ctx, self.params
+            n, m = p.n, p.m
+            self._x_h.numpy()[:] = x
+            self._x_d.view(-1).copy_(self._x_h, non_blocking=True)
+            cost, grad, con, jac = self._views
+            stream = torch.cuda.current_stream(ctx.device)
+            fn = ctx._lib.mpc_eval_fd_nz if self._structured else ctx._lib.mpc_eval_fd
+            _ffi.check(ctx._ctx, fn(ctx._ctx, self._tick_scc, self._x_d.data_ptr(), cost.data_ptr(), grad.data_ptr(),
+                                    con.data_ptr(), jac.data_ptr(), stream.cuda_stream))
+            self._out_h.copy_(self._out_d, non_blocking=True)
+            stream.synchronize()
+            o = self._out_h.numpy()
+            f = float(o[0])
+            if not np.isfinite(f):
+                raise ValueError("non-finite cost")      # a replacement must raise, not return NaN
+            if self._structured:
+                A = np.zeros((n + 1, m))
+                A.reshape(-1)[self._scatter] = o[1 + n + m:]
+                J = A[:n].T
+            else:
+                J = o[1 + n + m:].reshape(n, m).T.copy()
+            self._cache = (f, o[1:1 + n].copy(), o[1 + n:1 + n + m].copy(), J)
+            self._cache_key = key
+        return self._cache
 
     # ---- device plumbing ---------------------------------------------------------------------
     def _scenario(self, current_state, target_ee_pose, base_trajectory) -> ScenarioBatch:
@@ -244,8 +319,25 @@ class GpuURMPC:
             tl = self._world_to_base(-v_ind, yaw)
             ta = self._world_to_base(-base_state["angular_velocity"], yaw)
             current_state = self.dynamics.get_state_vector(current_joint_state, current_ee_pose)
-            base_trajectory = self.predict_base_motion(base_state, self.horizon)
-            self._J_cached = self.dynamics.get_jacobian(current_joint_state["position"]).copy()
+            # platform prediction and Jc = J(q) are made on the device straight into this controller's resident
+            # scenario (ur_mpc.py:154,157); only Jc comes back, for the DLS start
+            ctx = self._ctx
+            qb = self._qb_h.numpy()
+            qb[0:6] = current_joint_state["position"]
+            if self.use_dynamic_model:
+                if "v_cmd" in base_state or "omega_cmd" in base_state:
+                    raise ValueError("v_cmd/omega_cmd are not supported by the device predictor")
+                qb[6:18] = _pack_base(base_state)
+            self._qb_d.copy_(self._qb_h, non_blocking=True)
+            ctx.jacobian(self._qb_d[0:6].view(1, 6), out=self._jc_d)
+            if self.use_dynamic_model:
+                ctx.predict_base_dynamic(self._qb_d[6:18].view(1, 12), out=self._bt_d)
+            else:
+                bt = np.stack([_pack_base(b) for b in self._predict_base_kinematic(base_state, self.horizon)])
+                self._bt_d.copy_(torch.from_numpy(bt).view(1, self.horizon, 12))
+            self._jc_h.copy_(self._jc_d.view(-1), non_blocking=True)
+            torch.cuda.current_stream(ctx.device).synchronize()
+            self._J_cached = self._jc_h.numpy().reshape(6, 6).copy()
             J = np.vstack([self._J_cached[:3, :], self._J_cached[3:, :]])
             pinv = J.T @ np.linalg.inv(J @ J.T + 0.01 * np.eye(6))            # ur_mpc.py:173-175
             initial_vel = pinv @ np.concatenate([tl, ta])
@@ -254,13 +346,14 @@ class GpuURMPC:
                 x0[-6:] = initial_vel
             else:
                 x0 = np.tile(initial_vel, self.horizon)
-            sc = self._scenario(current_state, target_ee_pose, base_trajectory)
+            self._tick_scenario(current_state, target_ee_pose)
+            self._cache_key = None
+            ev = self._evaluate_tick
             result = minimize(
-                fun=lambda x: self._evaluate(x, sc)[0], x0=x0, method="SLSQP",
-                jac=lambda x: self._evaluate(x, sc)[1],                       # scipy's own FD, made on the device
+                fun=lambda x: ev(x)[0], x0=x0, method="SLSQP",
+                jac=lambda x: ev(x)[1],                                       # scipy's own FD, made on the device
                 bounds=self._get_bounds(x0),
-                constraints=[{"type": "ineq", "fun": lambda x: self._evaluate(x, sc)[2].copy(),
-                              "jac": lambda x: self._evaluate(x, sc)[3]}],
+                constraints=[{"type": "ineq", "fun": lambda x: ev(x)[2].copy(), "jac": lambda x: ev(x)[3]}],
                 options={"ftol": self.params.ftol, "maxiter": self.params.maxiter, "disp": self._disp})
             self.last_result = result
             if not result.success:

@@ -593,3 +593,25 @@ def test_qp_step_rejects_an_index_outside_the_state_rows():
     for k in (0, 3):                                                  # rows that no request named are untouched
         assert torch.equal(L[k], before[0][k]) and torch.equal(R[k], before[1][k]) and torch.equal(V[k], before[2][k])
     assert float(L[1].abs().sum()) > 0 and float(s_out[0].abs().sum()) > 0 and float(s_out[1].abs().sum()) == 0
+
+
+def test_prepare_tick_rejects_an_in_place_warm_start_shift():
+    """x0[i] = prev_solution[i + 6]: the same buffer for both would be read after it was overwritten."""
+    import ctypes as C
+
+    from mpc_amd import _ffi
+    from mpc_amd.batch import MpcContext
+
+    mp = MpcParams.reference_yaml_defaults(horizon=3)
+    N = 4
+    ctx = MpcContext(mp, N, 0)
+    z = lambda *shape: torch.zeros(shape, dtype=torch.float64, device=ctx.device)
+    q, ee, base, prev = z(N, 6), z(N, 6), z(N, 12), z(N, mp.n)
+    has = torch.ones(N, dtype=torch.uint8, device=ctx.device)
+    st, bt, jc, ui = z(N, 18), z(N, 3, 12), z(N, 36), z(N, 6)
+    act = torch.zeros(N, dtype=torch.uint8, device=ctx.device)
+    dyn = mp.base_dyn_array()
+    rc = ctx._lib.mpc_prepare_tick(ctx._ctx, N, q.data_ptr(), None, ee.data_ptr(), base.data_ptr(),
+                                   dyn.ctypes.data_as(C.POINTER(C.c_double)), prev.data_ptr(), has.data_ptr(), st.data_ptr(),
+                                   bt.data_ptr(), jc.data_ptr(), ui.data_ptr(), prev.data_ptr(), act.data_ptr(), ctx._stream())
+    assert rc == -1 and b"overlap" in ctx._lib.mpc_last_error(ctx._ctx)
