@@ -49,6 +49,12 @@ struct PrefixArgs {
 //   kCompact FD for long horizons: the non-zeros go to a global workspace, expand_kernel writes dc/dx
 enum Mode { kEval = 0, kFused = 1, kCompact = 2 };
 
+// Per-step records that the perturbed rollouts read with a different step in every group of six lanes are 14 doubles
+// apart, not 12: with 96-byte records steps k and k + 8 start in the same LDS bank (2-way conflicts on a fifth of
+// the reads), with 112-byte records ten consecutive steps start in ten different banks four apart.
+constexpr int kBtStride = 14;    // platform trajectory: [P(3), cos yaw, sin yaw, yaw, V(3), Omega(3), pad(2)]
+constexpr int kScsStride = 14;   // sin[6], cos[6] of the joint angles, pad(2)
+
 // LDS layout of one scenario (offsets in doubles)
 struct Layout {
     int xs, bt, ys, st0, tgt, Jc, up, scs, po, qs, qn, Cp, vv, tb, lb, jvel, jpos, total;
@@ -59,13 +65,13 @@ __host__ __device__ inline Layout make_layout(int H, int mode, bool same_dt)
     Layout Y;
     int o = 0;
     Y.xs = o;   o += 6 * H;         // control sequence
-    Y.bt = o;   o += 12 * H;        // platform trajectory
-    Y.ys = o;   o += 2 * H;         // cos, sin of the platform yaw per step
+    Y.bt = o;   o += kBtStride * H; // platform trajectory; cos / sin of the yaw replace roll and pitch, which nothing reads
+    Y.ys = Y.bt + 3;                // cos, sin of the platform yaw of step k at ys + kBtStride k
     Y.st0 = o;  o += 18;
     Y.tgt = o;  o += 6;
     Y.Jc = o;   o += 36;
     Y.up = o;   o += 6;
-    Y.scs = o;  o += 12 * (H + 1);  // sin[6], cos[6] of the unperturbed joint angles per step
+    Y.scs = o;  o += kScsStride * (H + 1);  // sin[6], cos[6] of the unperturbed joint angles per step
     Y.po = o;   o += 6 * (H + 1);   // unperturbed end-effector pose per step
     Y.qs = o;   o += 6 * (H + 1);   // unperturbed joint angles, cost rollout (dt_cost)
     Y.qn = o;   o += same_dt ? 0 : 6 * (H + 1);  // same, constraint rollout (dt_con)
@@ -266,8 +272,9 @@ __global__ __launch_bounds__(MAXT) void prefix_kernel(const mpc_params P, const 
     }
     for (int f = tid; f < ns * 12 * H; f += bs) {
         const int ls = f / (12 * H);
-        scen[ls * Y.total + Y.bt + (f - ls * 12 * H)] =
-            A.sc.base_traj[ROWS ? row(ls) * 12 * H + (f - ls * 12 * H) : (size_t)s0 * 12 * H + f];
+        const int e = f - ls * 12 * H, k = e / 12;
+        scen[ls * Y.total + Y.bt + kBtStride * k + (e - 12 * k)] =
+            A.sc.base_traj[ROWS ? row(ls) * 12 * H + e : (size_t)s0 * 12 * H + f];
     }
     for (int f = tid; f < ns * 18; f += bs)
         scen[(f / 18) * Y.total + Y.st0 + f % 18] = A.sc.state0[ROWS ? row(f / 18) * 18 + f % 18 : (size_t)s0 * 18 + f];
@@ -284,9 +291,9 @@ __global__ __launch_bounds__(MAXT) void prefix_kernel(const mpc_params P, const 
         const int ls = f / H, k = f - ls * H;
         double *S = scen + ls * Y.total;
         double sy, cy;
-        sincos_small(S[Y.bt + 12 * k + 5], &sy, &cy);
-        S[Y.ys + 2 * k] = cy;
-        S[Y.ys + 2 * k + 1] = sy;
+        sincos_small(S[Y.bt + kBtStride * k + 5], &sy, &cy);
+        S[Y.ys + kBtStride * k] = cy;
+        S[Y.ys + kBtStride * k + 1] = sy;
     }
 
     // ================= phase 1: the unperturbed rollout, one lane per step =====================
@@ -315,8 +322,8 @@ __global__ __launch_bounds__(MAXT) void prefix_kernel(const mpc_params P, const 
             sincos_small(qc[j], &sn[j], &cs[j]);
             S1[Y.qs + 6 * k + j] = qc[j];
             if (!SAME_DT) S1[Y.qn + 6 * k + j] = qn[j];
-            S1[Y.scs + 12 * k + j] = sn[j];
-            S1[Y.scs + 12 * k + 6 + j] = cs[j];
+            S1[Y.scs + kScsStride * k + j] = sn[j];
+            S1[Y.scs + kScsStride * k + 6 + j] = cs[j];
         }
         const int ku = (k < H) ? k : H - 1;
 #pragma unroll
@@ -361,8 +368,8 @@ __global__ __launch_bounds__(MAXT) void prefix_kernel(const mpc_params P, const 
 #pragma unroll
         for (int c = 0; c < 3; ++c) { S1[Y.po + 6 * k + c] = p[c]; S1[Y.po + 6 * k + 3 + c] = o[c]; }
         const int kb = (k < H) ? k : H - 1;                // terminal uses B_{H-1} (MPC:689)
-        const double Lk = unit_cost(P, k < H, vc1, u1, p, o, S1 + Y.bt + 12 * kb, S1[Y.ys + 2 * kb],
-                                    S1[Y.ys + 2 * kb + 1], S1 + Y.tgt, dec[kb], k > 0 && k < H && has_prev1,
+        const double Lk = unit_cost(P, k < H, vc1, u1, p, o, S1 + Y.bt + kBtStride * kb, S1[Y.ys + kBtStride * kb],
+                                    S1[Y.ys + kBtStride * kb + 1], S1 + Y.tgt, dec[kb], k > 0 && k < H && has_prev1,
                                     S1 + Y.up, k > 0 && k < H && H > 1);
         S1[Y.lb + k] = Lk;
     }
@@ -428,7 +435,7 @@ __global__ __launch_bounds__(MAXT) void prefix_kernel(const mpc_params P, const 
         for (int c = 0; c < 6; ++c) {
             const double ub = S2[Y.xs + 6 * ku + c];
             u[c] = (c == a && ku == j) ? xv : ub;
-            const double sb = S2[Y.scs + 12 * k + c], cb = S2[Y.scs + 12 * k + 6 + c];
+            const double sb = S2[Y.scs + kScsStride * k + c], cb = S2[Y.scs + kScsStride * k + 6 + c];
             sn[c] = (c == a) ? sa : sb;
             cs[c] = (c == a) ? ca : cb;
         }
@@ -441,8 +448,8 @@ __global__ __launch_bounds__(MAXT) void prefix_kernel(const mpc_params P, const 
             const double vs = fma(S2[Y.Jc + 6 * c + a], du, S2[Y.vv + 6 * ku + c]);
             V[c] = (k < H) ? vs : w[c];
         }
-        const double Lk = unit_cost(P, k < H, V, u, p, o, S2 + Y.bt + 12 * ku, S2[Y.ys + 2 * ku],
-                                    S2[Y.ys + 2 * ku + 1], S2 + Y.tgt, dec[ku], k > 0 && k < H && has_prev2,
+        const double Lk = unit_cost(P, k < H, V, u, p, o, S2 + Y.bt + kBtStride * ku, S2[Y.ys + kBtStride * ku],
+                                    S2[Y.ys + kBtStride * ku + 1], S2 + Y.tgt, dec[ku], k > 0 && k < H && has_prev2,
                                     S2 + Y.up, k > 0 && k < H && H > 1);
         acc = acc + Lk;
         if (k < H) {

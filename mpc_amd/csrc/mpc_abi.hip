@@ -209,7 +209,11 @@ int mpc_set_params(mpc_ctx *ctx, const mpc_params *p, const double *decay_host, 
         ctx->work_doubles = want;
     }
     if (want && !ctx->pipe.aux) {
-        MPC_HIP(ctx, hipStreamCreateWithFlags(&ctx->pipe.aux, hipStreamNonBlocking));
+        // the expansion (a store-bound fill) runs here beside the next chunk's rollouts: highest priority, so that its
+        // workgroups are dispatched first and the stores never wait for a CU slot behind compute-bound waves
+        int prio_low = 0, prio_high = 0;
+        MPC_HIP(ctx, hipDeviceGetStreamPriorityRange(&prio_low, &prio_high));
+        MPC_HIP(ctx, hipStreamCreateWithPriority(&ctx->pipe.aux, hipStreamNonBlocking, prio_high));
         for (int h = 0; h < 2; ++h) {
             MPC_HIP(ctx, hipEventCreateWithFlags(&ctx->pipe.filled[h], hipEventDisableTiming));
             MPC_HIP(ctx, hipEventCreateWithFlags(&ctx->pipe.drained[h], hipEventDisableTiming));

@@ -76,6 +76,51 @@ def eval_cases():
     return cases
 
 
+def h100_angular_cases():
+    """BASELINE configs[3]'s horizon with the revolute platform: f, c, scipy's FD gradient AND dc/dx of the reference
+    at H=100 (one case with previous_control and variables on / near the bounds).  ~1 minute per case."""
+    H = 100
+    mp = MpcParams.reference_yaml_defaults(horizon=H)
+    kin = OracleKinematics(COracle(ref_params_from(mp)))
+    cases = []
+    for with_prev in (False, True):
+        hs = make_scenarios(mp, kin, 2, motion="angular", cfg_id=100 + H, with_prev=with_prev)
+        i = 1 if with_prev else 0
+        x = hs.x[i].copy()
+        if with_prev:
+            lim = np.tile(np.asarray(mp.v_lim), H)
+            x[0] = lim[0]
+            x[7] = lim[7] - 5e-4
+            x[6 * H - 1] = -lim[6 * H - 1]
+        ref = _ref_for(H)
+        ref._J_cached = np.array(hs.Jc[i].reshape(6, 6))
+        if with_prev:
+            ref.previous_control = hs.u_prev[i].copy()
+        state0 = hs.state0[i].copy()
+        target = {"position": hs.target[i, :3].copy(), "orientation": hs.target[i, 3:].copy()}
+        bt = base_traj_from_array(hs.base_traj[i])
+        fun = lambda z: ref._cost_function(z, state0, target, bt)
+        con = ref._get_constraints(state0, bt)[0]["fun"]
+        bnds = ref._get_bounds(x)
+        lb = np.array([b[0] for b in bnds]); ub = np.array([b[1] for b in bnds])
+        t0 = time.time()
+        f0 = fun(x); c0 = con(x)
+        g = approx_derivative(fun, x, method="2-point", abs_step=1e-3, f0=f0, bounds=(lb, ub))
+        a = approx_derivative(con, x, method="2-point", abs_step=1e-3, f0=c0, bounds=(lb, ub))
+        print(f"H={H} angular prev={with_prev}: f={f0:.6f} ({time.time()-t0:.1f}s)", flush=True)
+        cases.append(dict(H=H, motion="angular", with_prev=with_prev, x=x, state0=state0, target=hs.target[i].copy(),
+                          base_traj=hs.base_traj[i].copy(), Jc=hs.Jc[i].copy(),
+                          u_prev=hs.u_prev[i].copy() if with_prev else np.zeros(6), f=f0, c=c0, grad=np.atleast_1d(g), jac=a))
+    cs = cases
+    np.savez_compressed(
+        os.path.join(OUT, "eval_H100_angular.npz"), H=np.int64(H), motion=np.array([c["motion"] for c in cs]),
+        with_prev=np.array([c["with_prev"] for c in cs], dtype=np.uint8), x=np.stack([c["x"] for c in cs]),
+        state0=np.stack([c["state0"] for c in cs]), target=np.stack([c["target"] for c in cs]),
+        base_traj=np.stack([c["base_traj"] for c in cs]), Jc=np.stack([c["Jc"] for c in cs]),
+        u_prev=np.stack([c["u_prev"] for c in cs]), f=np.array([c["f"] for c in cs]), c=np.stack([c["c"] for c in cs]),
+        grad=np.stack([c["grad"] for c in cs]), jac=np.stack([c["jac"] for c in cs]))
+
+
 def save_eval(cases):
     byH = {}
     for c in cases:
@@ -251,10 +296,14 @@ def main():
     if "--h20" in sys.argv:          # only the configs[2] solve fixtures (the others stay as committed)
         h20_cases()
         return
+    if "--h100" in sys.argv:         # only the configs[3] angular eval fixture
+        h100_angular_cases()
+        return
     base_motion_cases()
     save_eval(eval_cases())
     save_solve(solve_cases())
     h20_cases()
+    h100_angular_cases()
 
 
 if __name__ == "__main__":

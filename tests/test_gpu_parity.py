@@ -103,6 +103,74 @@ def test_against_reference_golden(golden_dir, algo, H):
     _compare(res, g["f"], g["grad"], g["c"], jac)
 
 
+@pytest.mark.parametrize("algo", ALGOS)
+def test_against_reference_golden_h100_angular(golden_dir, algo):
+    """configs[3]'s horizon with the revolute platform: f, c, grad f and the full dc/dx of the REAL reference at H=100
+    (tests/golden/eval_H100_angular.npz, oracle/gen_golden.py --h100), zero pattern included."""
+    path = os.path.join(golden_dir, "eval_H100_angular.npz")
+    if not os.path.exists(path):
+        pytest.fail("eval_H100_angular.npz missing: python -m oracle.gen_golden --h100 (where /root/reference exists)")
+    g = np.load(path, allow_pickle=False)
+    mp = params_for(100, algo=algo)
+    if not _supported(mp):
+        pytest.skip("algo not available for these parameters")
+    N = g["x"].shape[0]
+    ctx = _ctx(mp, N)
+    from mpc_amd.batch import ScenarioBatch
+
+    sc = ScenarioBatch.from_numpy(ctx.device, g["state0"], g["target"], g["base_traj"], g["Jc"], g["u_prev"], g["with_prev"])
+    x = torch.as_tensor(g["x"], dtype=torch.float64).to(ctx.device)
+    res = ctx.eval_fd(sc, x)
+    torch.cuda.synchronize()
+    assert (g["motion"] == "angular").all() and g["jac"].shape == (N, mp.m, mp.n)
+    _compare(res, g["f"], g["grad"], g["c"], np.transpose(g["jac"], (0, 2, 1)))
+
+
+def test_full_size_h100_16384():
+    """BASELINE configs[3] at full size: 16,384 scenarios at H=100 with the dense dc/dx (95 GB of it; 288 GB of HBM).
+    (i) the pipelined two-stream route over the whole batch equals two half batches bit for bit (different chunking
+    of the workspace, different overlap), (ii) the structured form expands to the same matrix, (iii) a strided sample
+    equals the CPU oracle including dc/dx and its zero pattern, (iv) state 0 and the upper triangle are exact zeros."""
+    N, H = 16384, 100
+    mp = params_for(H)
+    ctx = _ctx(mp, N)
+    co, hs = host_scenarios(mp, N, motion="angular", cfg_id=4, with_prev=True)
+    sc, x = to_device(ctx, hs)
+    full = ctx.eval_fd(sc, x)
+    torch.cuda.synchronize()
+    assert full.con_jac.numel() * 8 > 95e9
+    h = N // 2
+    half_jac = torch.empty((h, mp.n, mp.m), dtype=torch.float64, device=ctx.device)
+    from mpc_amd.batch import EvalResult
+    for lo in (0, h):
+        part = ctx.eval_fd(sc.slice(lo, lo + h), x[lo:lo + h],
+                           out=EvalResult(torch.empty(h, dtype=torch.float64, device=ctx.device), None, None, half_jac))
+        torch.cuda.synchronize()
+        assert torch.equal(part.cost, full.cost[lo:lo + h]) and torch.equal(part.grad, full.grad[lo:lo + h])
+        assert torch.equal(part.con, full.con[lo:lo + h])
+        for a in range(0, h, 1024):                       # compare in slices: keeps the temporaries small
+            assert torch.equal(half_jac[a:a + 1024], full.con_jac[lo + a:lo + a + 1024])
+    z = ctx.eval_fd_nz(sc.slice(0, 2048), x[:2048])
+    ctx.expand_jacobian(z.con_jac_nz, out=half_jac[:2048])
+    torch.cuda.synchronize()
+    assert torch.equal(half_jac[:2048], full.con_jac[:2048]) and torch.equal(z.grad, full.grad[:2048])
+    del half_jac
+    idx = np.arange(5, N, 2731)                           # 6 scenarios
+    sub = {k: (None if v is None else v[idx]) for k, v in hs.as_oracle_dict().items()}
+    c_o, g_o, con_o, jac_o = co.eval_fd(sub)
+    tidx = torch.as_tensor(idx, device=ctx.device)
+    assert_cost_close(full.cost[tidx].cpu().numpy(), c_o)
+    assert_grad_close(full.grad[tidx].cpu().numpy(), g_o)
+    np.testing.assert_allclose(full.con[tidx].cpu().numpy(), con_o, rtol=1e-13, atol=1e-13)
+    got = full.con_jac[tidx].cpu().numpy()
+    np.testing.assert_allclose(got, jac_o, rtol=1e-9, atol=1e-10)
+    assert np.array_equal(got == 0.0, jac_o == 0.0)
+    J = full.con_jac[:256].view(256, H, 6, H + 1, 12)     # [s][j][a][k][row in state]
+    assert float(J[:, :, :, 0, :].abs().max()) == 0.0
+    upper = torch.arange(H + 1, device=ctx.device)[None, :] <= torch.arange(H, device=ctx.device)[:, None]
+    assert float(J.permute(0, 2, 4, 1, 3)[..., upper].abs().max()) == 0.0
+
+
 def test_device_kinematics_match_oracle():
     mp = params_for(20)
     co, hs = host_scenarios(mp, 64, motion="angular", cfg_id=12)
