@@ -193,19 +193,46 @@ def cpu_baseline(mp: MpcParams, hs, budget_s: float = 12.0):
     }
 
 
-def measured_traffic(H, S, algo):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, the
-    gfx950 correction of MI355X_MICROARCH.md), if a measurement of this exact configuration exists."""
+def _profile_entries(name):
+    """Entries of profiles/*/<name> (newest round first); a file holds one entry or a list of them."""
     import glob
 
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "traffic.json")), reverse=True):
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", name)), reverse=True):
         try:
             t = json.load(open(path))
         except Exception:
             continue
-        if t.get("horizon") == H and t.get("scenarios") == S and t.get("algo") == algo:
-            return float(t["traffic_bytes_per_launch"]), os.path.relpath(path, ROOT)
+        for e in (t if isinstance(t, list) else [t]):
+            yield e, os.path.relpath(path, ROOT)
+
+
+def measured_traffic(H, S, algo, variant="jac"):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, the
+    gfx950 correction of MI355X_MICROARCH.md), if a measurement of this exact configuration exists."""
+    for t, src in _profile_entries("traffic.json"):
+        if (t.get("horizon") == H and t.get("scenarios") == S and t.get("algo") == algo
+                and t.get("variant", "jac") == variant):
+            return float(t["traffic_bytes_per_launch"]), src
     return None, None
+
+
+def executed_fp64(H, S, variant, kernel_ms):
+    """FP64 operations the kernel EXECUTED, from the committed counter passes of this kernel variant at this horizon
+    (64 x (ADD + MUL + 2 FMA + TRANS) wavefront instructions; per scenario the count does not depend on the batch),
+    over the live kernel time: what the hardware did, against the vector-FP64 peak.  None without a profile."""
+    wanted = (variant, "rollout") if H > 40 else (variant,)      # long horizons: one rollout kernel serves every variant
+    for t, src in _profile_entries("executed_fp64.json"):
+        if t.get("horizon") == H and t.get("variant") in wanted and "expand" not in t.get("kernel", ""):
+            flops = float(t["executed_flops_per_launch"]) / float(t["scenarios"]) * S
+            tf = flops / (kernel_ms * 1e-3) / 1e12
+            return {"executed_tflops": tf, "executed_frac_of_fp64_valu_peak": tf / FP64_VALU_PEAK_TF,
+                    "executed_flops_per_eval": flops / S, "lane_occupancy": t.get("lane_occupancy"), "source": src}
+    return {"executed_tflops": None, "executed_frac_of_fp64_valu_peak": None, "source": None}
+
+
+ALGORITHMIC_NOTE = ("full-rollout count of SURVEY.md 8(d), (1+6H)(745H+600+30(H+1)) per eval; the prefix kernel shares the "
+                    "unperturbed prefix of every perturbed rollout and executes less, so this is a rate of useful work, "
+                    "not a fraction of the hardware peak")
 
 
 def single_tick_latency(device, with_cpu):
@@ -528,6 +555,10 @@ def main():
         achieved = abytes * S / (kernel_ms * 1e-3) / 1e9
         algo_name = "prefix" if ctx.params.algo != _ffi.ALGO_ROLLOUT else "rollout"
         traffic, traffic_src = measured_traffic(H, S, algo_name)
+        if traffic is None and H > 40:       # long horizons: the rollout kernel and the expansion are two kernels
+            parts = [measured_traffic(H, S, algo_name, v) for v in ("rollout", "expand")]
+            if all(p[0] is not None for p in parts):
+                traffic, traffic_src = sum(p[0] for p in parts), parts[0][1]
         line = {
             "metric": "objective+gradient evals/sec (f, c, FD grad f, dense FD dc/dx per scenario)",
             "value": value, "unit": "evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -542,8 +573,9 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": abytes * S,
                          "kernel_ms": kernel_ms, "algorithmic_bytes_per_eval": abytes,
-                         "fp64_valu": {"achieved_tflops_algorithmic": aflops * S / (kernel_ms * 1e-3) / 1e12,
-                                       "peak_tflops": FP64_VALU_PEAK_TF, "algorithmic_flops_per_eval": aflops}},
+                         "fp64_valu": dict(executed_fp64(H, S, "jac", kernel_ms), peak_tflops=FP64_VALU_PEAK_TF,
+                                           algorithmic_tflops=aflops * S / (kernel_ms * 1e-3) / 1e12,
+                                           algorithmic_flops_per_eval=aflops, algorithmic_note=ALGORITHMIC_NOTE)},
         }
         # compute-side view: same evals without the dense dc/dx stream (gradient + constraints only)
         extras = not args.only_main
@@ -559,9 +591,9 @@ def main():
         torch.cuda.synchronize()
         ms_nj = e0.elapsed_time(e1) / args.steps
         if extras:
-            line["no_dense_jacobian"] = {"evals_per_s": S / (ms_nj * 1e-3), "kernel_ms": ms_nj,
-                                     "fp64_tflops_algorithmic": aflops * S / (ms_nj * 1e-3) / 1e12,
-                                     "frac_of_fp64_valu_peak": aflops * S / (ms_nj * 1e-3) / 1e12 / FP64_VALU_PEAK_TF}
+            line["no_dense_jacobian"] = dict({"evals_per_s": S / (ms_nj * 1e-3), "kernel_ms": ms_nj,
+                                              "algorithmic_tflops": aflops * S / (ms_nj * 1e-3) / 1e12},
+                                             **executed_fp64(H, S, "nojac", ms_nj))
         if extras and ctx.nz_supported():
             # same derivative information with dc/dx in its structured form (include/mpc_amd.h, mpc_eval_fd_nz):
             # 11 KB instead of 242 KB per eval at H=20, so this figure is bound by the FP64 pipes, not HBM
@@ -573,10 +605,10 @@ def main():
             e1.record()
             torch.cuda.synchronize()
             ms_nz = e0.elapsed_time(e1) / args.steps
-            line["structured_jacobian"] = {"evals_per_s": S / (ms_nz * 1e-3), "kernel_ms": ms_nz,
-                                           "bytes_out_per_eval": 8 * (1 + mp.n + mp.m + ctx.nz_count),
-                                           "fp64_tflops_algorithmic": aflops * S / (ms_nz * 1e-3) / 1e12,
-                                           "frac_of_fp64_valu_peak": aflops * S / (ms_nz * 1e-3) / 1e12 / FP64_VALU_PEAK_TF}
+            line["structured_jacobian"] = dict({"evals_per_s": S / (ms_nz * 1e-3), "kernel_ms": ms_nz,
+                                                "bytes_out_per_eval": 8 * (1 + mp.n + mp.m + ctx.nz_count),
+                                                "algorithmic_tflops": aflops * S / (ms_nz * 1e-3) / 1e12},
+                                               **executed_fp64(H, S, "nz", ms_nz))
             del z
         if extras and S > 4096:   # configs[1] of BASELINE.json: 4,096 scenarios on one GPU
             sc4, x4 = sc.slice(0, 4096), x[:4096]
