@@ -117,7 +117,17 @@ qp_step_kernel(int H, int count, int rows, const int32_t *__restrict__ index, co
             T.sync();
             PAR_FOR(T, i, 0, n) W.E[i * n - (i * (i - 1)) / 2] = 1.0;
         } else {
-            PAR_FOR(T, e, 0, ldl - 1) W.E[e] = l[e];
+            // the factor comes from global memory: sixteen loads in flight per thread, not one
+            const int per = 16 * (int)blockDim.x;
+            int e0 = 0;
+            for (; e0 + per <= ldl - 1; e0 += per) {
+                double t[16];
+#pragma unroll
+                for (int q = 0; q < 16; ++q) t[q] = l[e0 + q * (int)blockDim.x + (int)threadIdx.x];
+#pragma unroll
+                for (int q = 0; q < 16; ++q) W.E[e0 + q * (int)blockDim.x + (int)threadIdx.x] = t[q];
+            }
+            for (int e = e0 + (int)threadIdx.x; e < ldl - 1; e += (int)blockDim.x) W.E[e] = l[e];
         }
         if (fl & 2) {
             PAR_FOR(T, i, 0, n) {
@@ -176,6 +186,9 @@ namespace mpck {
 
 int qp_teams_per_cu(int H)
 {
+#ifdef MPC_QP_TEAMS_PER_CU          // development: measure a team without a neighbour on its CU
+    return MPC_QP_TEAMS_PER_CU;
+#endif
     const size_t b = lds_bytes(H);
     if (!b) return 4;
     const int t = (int)(kQpLdsLimit / b);

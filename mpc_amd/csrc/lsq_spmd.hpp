@@ -178,27 +178,35 @@ SPMD_HD int nnls(const Team &T, const Work &W, int mrow, int ncol, int mg, doubl
     for (;;) {
         // ---- L110: dual variables of the columns still in Z
         if (iz1 > iz2 || nsetp >= m) break;
-        PAR_FOR(T, t, iz1 - 1, iz2) {
-            const int j = index[t];
-            double s = 0.0;
+        // two columns per thread at a time: twice as many loads in flight from the matrix (global memory), each
+        // column's sum still in the order of its rows
+        for (int t = iz1 - 1 + T.tid(); t < iz2; t += 2 * T.size()) {
+            const int t2 = t + T.size();
+            const bool two = t2 < iz2;
+            const int j = index[t], j2 = two ? index[t2] : j;
+            double s = 0.0, s2 = 0.0;
             // a * (+-0.0) added to a sum that is never -0.0 changes nothing: rows where b is zero are not read.
             // Sixteen rows at a time, loads first, so that a thread does not wait for each load in turn.
             int r = npp1;
             for (; r + 15 <= m; r += 16) {
-                double bv[16], av[16];
+                double bv[16], av[16], av2[16];
                 SPMD_UNROLL
                 for (int q = 0; q < 16; ++q) bv[q] = b[r - 1 + q];
                 SPMD_UNROLL
-                for (int q = 0; q < 16; ++q) av[q] = bv[q] != 0.0 ? AT(r + q, j) : 0.0;
+                for (int q = 0; q < 16; ++q) {
+                    av[q] = bv[q] != 0.0 ? AT(r + q, j) : 0.0;
+                    av2[q] = bv[q] != 0.0 ? AT(r + q, j2) : 0.0;
+                }
                 SPMD_UNROLL
                 for (int q = 0; q < 16; ++q)
-                    if (bv[q] != 0.0) s = s + av[q] * bv[q];
+                    if (bv[q] != 0.0) { s = s + av[q] * bv[q]; s2 = s2 + av2[q] * bv[q]; }
             }
             for (; r <= m; ++r) {
                 const double br = b[r - 1];
-                if (br != 0.0) s = s + AT(r, j) * br;
+                if (br != 0.0) { s = s + AT(r, j) * br; s2 = s2 + AT(r, j2) * br; }
             }
             w[j - 1] = s;
+            if (two) w[j2 - 1] = s2;
         }
         T.sync();
         QP_MARK(T, 16);   // NNLS: dual pass
