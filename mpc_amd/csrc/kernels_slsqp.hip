@@ -21,23 +21,27 @@ namespace {
 
 // the BLAS-1 helpers of slsqp_core.c (same operation order; ddot's five-fold unrolling there adds its terms left to
 // right, i.e. in this order)
-__device__ __forceinline__ double ddot_sl(int n, const double *dx, int, const double *dy, int)
+__device__ __forceinline__ double ddot_sl(int n, const double *__restrict__ dx, int, const double *__restrict__ dy, int)
 {
     double t = 0.0;
+#pragma unroll 8
     for (int i = 0; i < n; ++i) t = t + dx[i] * dy[i];
     return t;
 }
-__device__ __forceinline__ void daxpy_sl(int n, double da, const double *dx, int, double *dy, int)
+__device__ __forceinline__ void daxpy_sl(int n, double da, const double *__restrict__ dx, int, double *__restrict__ dy, int)
 {
     if (n <= 0 || da == 0.0) return;
+#pragma unroll 8
     for (int i = 0; i < n; ++i) dy[i] = dy[i] + da * dx[i];
 }
-__device__ __forceinline__ void dcopy_(int n, const double *dx, int, double *dy, int)
+__device__ __forceinline__ void dcopy_(int n, const double *__restrict__ dx, int, double *__restrict__ dy, int)
 {
+#pragma unroll 8
     for (int i = 0; i < n; ++i) dy[i] = dx[i];
 }
 __device__ __forceinline__ void dscal_sl(int n, double da, double *dx, int)
 {
+#pragma unroll 8
     for (int i = 0; i < n; ++i) dx[i] = da * dx[i];
 }
 __device__ __forceinline__ double dnrm2_(int n, const double *dx, int)
@@ -54,12 +58,18 @@ __device__ __forceinline__ double dnrm2_(int n, const double *dx, int)
     return scale * sqrt(ssq);
 }
 
-__device__ __forceinline__ void slsqp_body_device(int m, int meq, int la, int n, double *x, const double *xl, const double *xu, double f,
-                                  const double *c, const double *g, double *a, double *acc, int *iter, int *mode, const double *r,
-                                  double *l, double *x0, double *mu, double *s, double *u, double *v, double *w, int *iw,
-                                  slsqp_state *S)
+// (the vectors are distinct arrays: __restrict__ lets the compiler issue a loop's loads ahead of its stores)
+__device__ __forceinline__ void slsqp_body_device(int m, int meq, int la, int n, double *__restrict__ x,
+                                                  const double *__restrict__ xl, const double *__restrict__ xu, double f,
+                                                  const double *__restrict__ c, const double *__restrict__ g, double *a,
+                                                  double *acc, int *iter, int *mode, const double *__restrict__ r, double *l,
+                                                  double *__restrict__ x0, double *__restrict__ mu, double *__restrict__ s,
+                                                  double *__restrict__ u, double *__restrict__ v, double *w, int *iw,
+                                                  slsqp_state *S)
 #define SLSQP_BODY_FULL 0
+#define SLSQP_BODY_UNROLL _Pragma("unroll 8")
 #include "slsqp_body.inc"
+#undef SLSQP_BODY_UNROLL
 #undef SLSQP_BODY_FULL
 
 }  // namespace
@@ -110,7 +120,8 @@ __global__ void solve_begin_kernel(const mpc_params P, SolveWorkspace W, int cou
         W.ub[idx] = lim;
     }
     // lists of "round -1" (slot 0): every problem is waiting for its first call of the body
-    if (idx < 32) W.counters[idx] = (idx == 0 || idx == 3) ? count : 0;
+    // (the seed list is not a round of f requests: the running total starts at -count, see solve_body_kernel)
+    if (idx < 32) W.counters[idx] = (idx == 0 || idx == 3) ? count : (idx == 16 ? -count : 0);
     if (idx < (size_t)count) W.LIST_F[0][idx] = (int32_t)idx;
     if (idx >= (size_t)count * n) return;
     const int i = (int)(idx % n);
@@ -140,65 +151,106 @@ __global__ void solve_begin_kernel(const mpc_params P, SolveWorkspace W, int cou
 // the vectors the body reads are staged in LDS with coalesced loads, the first lane runs the body on them, the team
 // writes back what it changed.  What the problem asks for next goes to the new slot's lists.
 // counters, per slot s at [8 s ..]: +0 f requests, +1 derivative requests, +2 QP requests, +3 their total (= problems
-// still unfinished), +4 the QP kernel's work-queue head (the caller zeroes the new slot before the launch);
-// [16..18] running totals of the three kinds.
-__global__ __launch_bounds__(64) void solve_body_kernel(int H, SolveWorkspace W, int old)
+// still unfinished; written by solve_count_kernel), +4 the QP kernel's work-queue head (the caller zeroes the new slot
+// before the launch); [16..18] running totals of the three kinds over every round up to and including the old slot's
+// (the first workgroup adds the old slot's lengths).  One atomic per problem and round (its slot in a list): every problem of a lock-step round increments the same word,
+// and L2 serialises them.
+constexpr int kBodyWaves = 4;      // problems per workgroup of solve_body_kernel, one wavefront each (fewer if LDS is short)
+
+__global__ __launch_bounds__(64 * kBodyWaves) void solve_body_kernel(int H, SolveWorkspace W, int old)
 {
     extern __shared__ double body_lds[];
+    __shared__ int ask[kBodyWaves];          // what each wavefront's problem asks for: 0 f, 1 derivatives, 2 QP, -1 nothing
+    __shared__ int first[3];                 // first list position of this workgroup's requests, per kind
     const int32_t *co = W.counters + 8 * old;
     int32_t *cn = W.counters + 8 * (1 - old);
     const int cF = co[0], cG = co[1], cQ = co[2];
-    int k = (int)blockIdx.x, p;
+    if (blockIdx.x == 0 && threadIdx.x < 3) W.counters[16 + threadIdx.x] += co[threadIdx.x];   // the round just served
+    const int n = 6 * H, m = 12 * (H + 1), mg = m + 2 * n, lane = (int)(threadIdx.x & 63u), wave = (int)(threadIdx.x >> 6);
+    const int waves = (int)(blockDim.x >> 6);
+    int k = (int)blockIdx.x * waves + wave, p = -1;
     if (k < cF) p = W.LIST_F[old][k];
     else if ((k -= cF) < cG) p = W.LIST_G[old][k];
     else if ((k -= cG) < cQ) p = W.LIST_Q[old][k];
-    else return;
-    const int n = 6 * H, m = 12 * (H + 1), mg = m + 2 * n, lane = (int)threadIdx.x;
-    double *x = body_lds, *x0 = x + n, *s = x0 + n, *u = s + n, *v = u + n, *g = v + n, *c = g + n, *mu = c + m, *r = mu + m;
-    double *gx = W.X + (size_t)p * n, *gx0 = W.X0 + (size_t)p * n, *gs = W.S + (size_t)p * n, *gmu = W.MU + (size_t)p * m;
-    {
-        const double *gg = W.G + (size_t)p * n, *gc = W.C + (size_t)p * m, *gr = W.RM + (size_t)p * mg;
-        for (int i = lane; i < n; i += 64) { x[i] = gx[i]; x0[i] = gx0[i]; s[i] = gs[i]; g[i] = gg[i]; }
-        for (int i = lane; i < m; i += 64) { c[i] = gc[i]; mu[i] = gmu[i]; r[i] = gr[i]; }
+    const bool live = p >= 0;                // a wavefront beyond the lists only takes part in the barriers
+    const size_t per = (size_t)(6 * n + 3 * m);
+    double *x = body_lds + wave * per, *x0 = x + n, *s = x0 + n, *u = s + n, *v = u + n, *g = v + n, *c = g + n, *mu = c + m,
+           *r = mu + m;
+    const size_t pp = live ? (size_t)p : 0;
+    double *gx = W.X + pp * n, *gx0 = W.X0 + pp * n, *gs = W.S + pp * n, *gmu = W.MU + pp * m;
+    if (live) {
+        // every load of up to 256 entries of the seven vectors is issued before the first LDS store: one trip to
+        // memory per pass (a single pass at H = 20) instead of one per vector and stride
+        const double *gg = W.G + pp * n, *gc = W.C + pp * m, *gr = W.RM + pp * mg;
+        for (int base = 0; base < m; base += 256) {
+            double rx[4], rx0[4], rs[4], rg[4], rc[4], rmu[4], rr[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int i = base + 64 * q + lane;
+                const bool in_n = i < n, in_m = i < m;
+                rx[q] = in_n ? gx[i] : 0.0;
+                rx0[q] = in_n ? gx0[i] : 0.0;
+                rs[q] = in_n ? gs[i] : 0.0;
+                rg[q] = in_n ? gg[i] : 0.0;
+                rc[q] = in_m ? gc[i] : 0.0;
+                rmu[q] = in_m ? gmu[i] : 0.0;
+                rr[q] = in_m ? gr[i] : 0.0;
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int i = base + 64 * q + lane;
+                if (i < n) { x[i] = rx[q]; x0[i] = rx0[q]; s[i] = rs[q]; g[i] = rg[q]; }
+                if (i < m) { c[i] = rc[q]; mu[i] = rmu[q]; r[i] = rr[q]; }
+            }
+        }
     }
     __syncthreads();
     if (lane == 0) {
-        int mode = W.MODE[p];
-        slsqp_state S = W.ST[p];
-        if (mode == MPC_SLSQP_MODE_QP) S.qp_mode = W.QPMODE[p];
-        int iter = W.ITER[p];
-        double acc = W.ACC[p];
-        slsqp_body_device(m, 0, m, n, x, W.lb, W.ub, W.F[p], c, g, nullptr, &acc, &iter, &mode, r, nullptr, x0, mu, s, u, v, nullptr,
-                          nullptr, &S);
-        W.ST[p] = S;
-        W.ITER[p] = iter;
-        W.ACC[p] = acc;
-        W.MODE[p] = mode;
-        int slot = -1;
-        if (mode == 1 || mode == -1) {
-            const int kind = mode == 1 ? 0 : 1;
-            slot = atomicAdd(&cn[kind], 1);
-            (kind == 0 ? W.LIST_F : W.LIST_G)[1 - old][slot] = p;
-            atomicAdd(&W.counters[16 + kind], 1);
-            atomicAdd(&cn[3], 1);
-        } else if (mode == MPC_SLSQP_MODE_QP) {
-            W.QPFLAGS[p] = (S.qp_reset ? 1 : 0) | (S.qp_bfgs ? 2 : 0);
-            slot = atomicAdd(&cn[2], 1);
-            W.LIST_Q[1 - old][slot] = p;
-            atomicAdd(&W.counters[18], 1);
-            atomicAdd(&cn[3], 1);
-        }                                                           // else: finished, MODE[p] is the exit mode
-        reinterpret_cast<int *>(body_lds + 6 * n + 3 * m)[0] = mode;
+        int kind = -1;
+        if (live) {
+            int mode = W.MODE[p];
+            slsqp_state S = W.ST[p];
+            if (mode == MPC_SLSQP_MODE_QP) S.qp_mode = W.QPMODE[p];
+            int iter = W.ITER[p];
+            double acc = W.ACC[p];
+            slsqp_body_device(m, 0, m, n, x, W.lb, W.ub, W.F[p], c, g, nullptr, &acc, &iter, &mode, r, nullptr, x0, mu, s, u, v,
+                              nullptr, nullptr, &S);
+            W.ST[p] = S;
+            W.ITER[p] = iter;
+            W.ACC[p] = acc;
+            W.MODE[p] = mode;                                       // not 1, -1 or QP: finished, this is the exit mode
+            if (mode == 1) kind = 0;
+            else if (mode == -1) kind = 1;
+            else if (mode == MPC_SLSQP_MODE_QP) {
+                kind = 2;
+                W.QPFLAGS[p] = (S.qp_reset ? 1 : 0) | (S.qp_bfgs ? 2 : 0);
+            }
+        }
+        ask[wave] = kind;
     }
     __syncthreads();
-    const int mode = reinterpret_cast<const int *>(body_lds + 6 * n + 3 * m)[0];
+    // one atomic per kind and WORKGROUP reserves the list positions of its requests (every problem of a lock-step round
+    // increments the same word, and L2 serialises them)
+    if (threadIdx.x < 3) {
+        int count = 0;
+        for (int w = 0; w < waves; ++w) count += ask[w] == (int)threadIdx.x;
+        first[threadIdx.x] = count ? atomicAdd(&cn[threadIdx.x], count) : 0;
+    }
+    __syncthreads();
+    const int kind = ask[wave];
+    if (!live) return;
+    if (lane == 0 && kind >= 0) {
+        int slot = first[kind];
+        for (int w = 0; w < wave; ++w) slot += ask[w] == kind;
+        (kind == 0 ? W.LIST_F : kind == 1 ? W.LIST_G : W.LIST_Q)[1 - old][slot] = p;
+    }
     for (int i = lane; i < n; i += 64) { gx[i] = x[i]; gx0[i] = x0[i]; gs[i] = s[i]; }
     for (int i = lane; i < m; i += 64) gmu[i] = mu[i];
-    if (mode == MPC_SLSQP_MODE_QP) {
-        double *gu = W.LO + (size_t)p * n, *gv = W.HI + (size_t)p * n;
+    if (kind == 2) {
+        double *gu = W.LO + pp * n, *gv = W.HI + pp * n;
         for (int i = lane; i < n; i += 64) { gu[i] = u[i]; gv[i] = v[i]; }
-    } else if (mode == 1 || mode == -1) {
-        double *xe = W.XE + (size_t)p * n;                          // the point to evaluate, inside the box (_clip_x_for_func)
+    } else if (kind >= 0) {
+        double *xe = W.XE + pp * n;                                 // the point to evaluate, inside the box (_clip_x_for_func)
         for (int i = lane; i < n; i += 64) {
             double t = x[i];
             t = t < W.lb[i] ? W.lb[i] : t;
@@ -214,7 +266,10 @@ __global__ void solve_result_kernel(int H, SolveWorkspace W, int count, int slot
 {
     const int n = 6 * H;
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx < 4 && stats != nullptr) stats[idx] = idx < 3 ? W.counters[16 + idx] : W.counters[8 * slot + 3];
+    if (idx < 4 && stats != nullptr) {     // the latest slot's requests have been served but not yet added to the totals
+        const int32_t *c = W.counters + 8 * slot;
+        stats[idx] = idx < 3 ? W.counters[16 + idx] + c[idx] : c[0] + c[1] + c[2];
+    }
     if (idx >= (size_t)count * n) return;
     x[idx] = W.X[idx];
     if (idx % n == 0) {
@@ -225,7 +280,8 @@ __global__ void solve_result_kernel(int H, SolveWorkspace W, int count, int slot
     }
 }
 
-__global__ void copy_i32_kernel(const int32_t *__restrict__ src, int32_t *__restrict__ dst) { *dst = *src; }
+// unfinished problems of a round = the lengths of its three request lists
+__global__ void solve_count_kernel(int32_t *__restrict__ c) { c[3] = c[0] + c[1] + c[2]; }
 
 }  // namespace
 
@@ -246,13 +302,17 @@ hipError_t launch_solve_body(int H, const SolveWorkspace &W, int bound, int old_
 {
     hipError_t e = hipMemsetAsync(W.counters + 8 * (1 - old_slot), 0, 8 * sizeof(int32_t), stream);
     if (e != hipSuccess || bound <= 0) return e;
-    const size_t lds = sizeof(double) * (size_t)(6 * 6 * H + 3 * 12 * (H + 1) + 2);
+    const size_t per = sizeof(double) * (size_t)(6 * 6 * H + 3 * 12 * (H + 1));
+    int waves = (int)((size_t)150 * 1024 / per);
+    waves = waves < 1 ? 1 : (waves > kBodyWaves ? kBodyWaves : waves);
+    const size_t lds = per * (size_t)waves;
     if (lds > 48 * 1024) {
         e = hipFuncSetAttribute(reinterpret_cast<const void *>(solve_body_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(solve_body_kernel, dim3((unsigned)bound), dim3(64), lds, stream, H, W, old_slot);
+    hipLaunchKernelGGL(solve_body_kernel, dim3((unsigned)((bound + waves - 1) / waves)), dim3(64 * waves), lds, stream, H, W,
+                       old_slot);
     return hipGetLastError();
 }
 
@@ -265,9 +325,9 @@ hipError_t launch_solve_result(int H, const SolveWorkspace &W, int count, int sl
     return hipGetLastError();
 }
 
-hipError_t launch_copy_i32(const int32_t *src, int32_t *dst, hipStream_t stream)
+hipError_t launch_solve_count(const SolveWorkspace &W, int slot, hipStream_t stream)
 {
-    hipLaunchKernelGGL(copy_i32_kernel, dim3(1), dim3(1), 0, stream, src, dst);
+    hipLaunchKernelGGL(solve_count_kernel, dim3(1), dim3(1), 0, stream, W.counters + 8 * slot);
     return hipGetLastError();
 }
 

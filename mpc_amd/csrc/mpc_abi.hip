@@ -551,6 +551,7 @@ int mpc_solve_rounds(mpc_ctx *ctx, const mpc_scenarios *sc, void *ws, int rows, 
         MPC_HIP(ctx, mpck::launch_qp_step_rows(ctx->horizon, ctx->qp_teams, rows, lq, W.QPFLAGS, W.LO, W.HI, W.S, W.L, W.G, W.C, W.NZ,
                                                W.RM, W.V, W.QPMODE, ctx->d_qp_work, ctx->d_qp_iwork, st));
     }
+    MPC_HIP(ctx, mpck::launch_solve_count(W, ctx->solve_slot, st));
     if (unfinished)
         MPC_HIP(ctx, hipMemcpyAsync(unfinished, W.counters + 8 * ctx->solve_slot + 3, sizeof(int32_t), hipMemcpyDefault, st));
     return MPC_OK;

@@ -93,7 +93,7 @@ hipError_t launch_solve_begin(const mpc_params &P, const SolveWorkspace &W, int 
 hipError_t launch_solve_body(int H, const SolveWorkspace &W, int bound, int old_slot, hipStream_t stream);
 hipError_t launch_solve_result(int H, const SolveWorkspace &W, int count, int slot, double *x, double *fun, int32_t *nit,
                                int32_t *status, int32_t *stats, hipStream_t stream);
-hipError_t launch_copy_i32(const int32_t *src, int32_t *dst, hipStream_t stream);
+hipError_t launch_solve_count(const SolveWorkspace &W, int slot, hipStream_t stream);
 // One request list of a device-resident solve: evaluate rows list[0 .. *count) of the per-problem arrays in place
 // (x from XE, outputs to the problem's own rows).  `bound` >= *count sizes the grid; surplus workgroups exit.
 struct RowList {

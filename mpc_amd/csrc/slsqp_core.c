@@ -635,7 +635,9 @@ void mpc_slsqpb(int m, int meq, int la, int n, double *x, double *xl, double *xu
                    double *acc, int *iter, int *mode, double *r, double *l, double *x0, double *mu, double *s, double *u,
                    double *v, double *w, int *iw, slsqp_state *S)
 #define SLSQP_BODY_FULL 1
+#define SLSQP_BODY_UNROLL
 #include "slsqp_body.inc"
+#undef SLSQP_BODY_UNROLL
 #undef SLSQP_BODY_FULL
 
 /* One reverse-communication call; arguments as scipy.optimize._slsqp.slsqp.  a is column-major (la, n+1). */
