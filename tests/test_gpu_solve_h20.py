@@ -36,10 +36,14 @@ def _solver(kind, ctx, N):
         return None
     if kind == "native":
         return NativeBatchedSLSQP(ctx, threads=3, capacity=N)
+    if kind == "resident":
+        from mpc_amd.device_solver import ResidentSLSQP
+
+        return ResidentSLSQP(ctx, capacity=N, lanes=2, min_per_lane=2)
     return DeviceQpSLSQP(ctx, threads=3, capacity=N, lanes=2, min_per_lane=2)     # two lanes even for 7 problems
 
 
-@pytest.mark.parametrize("kind", ["scipy_core", "native", "device_qp"])
+@pytest.mark.parametrize("kind", ["scipy_core", "native", "device_qp", "resident"])
 def test_h20_solves_match_reference(golden_dir, kind):
     from mpc_amd.solver import BatchedMPC
 
@@ -78,7 +82,7 @@ def test_h20_drop_in_class_matches_reference(golden_dir):
             np.testing.assert_allclose(u, g["control"][i, tick], rtol=0, atol=SOL_ATOL)
 
 
-@pytest.mark.parametrize("kind", ["scipy_core", "device_qp"])
+@pytest.mark.parametrize("kind", ["scipy_core", "device_qp", "resident"])
 def test_h20_closed_loop_matches_reference(golden_dir, kind):
     """Four ticks of the action server's loop at H=20 against the trajectory the real reference produced."""
     from mpc_amd.closed_loop import run_closed_loop
@@ -116,10 +120,11 @@ def test_closed_loop_survives_a_tick_on_which_every_controller_exits_early():
 
 
 def test_full_size_solves_65536_angular():
-    """configs[2] at full size through DeviceQpSLSQP: 65,536 angular-motion scenarios, H=20, one tick.
+    """configs[2] at full size through DeviceQpSLSQP and ResidentSLSQP: 65,536 angular-motion scenarios, H=20, one tick.
     Scenarios are independent optimisations, so (i) a permuted batch gives the permuted results bit for bit,
     (ii) a half batch equals that half of the full batch, (iii) everything past the early exit converges, and
     (iv) a strided sample equals the host-only driver (which is pinned call by call to scipy's core)."""
+    from mpc_amd.device_solver import ResidentSLSQP
     from mpc_amd.native_solver import DeviceQpSLSQP, NativeBatchedSLSQP
     from mpc_amd.scenarios import DeviceKinematics, make_scenarios, to_device
 
@@ -148,6 +153,13 @@ def test_full_size_solves_65536_angular():
         half = dev.solve(gather(keep[h:]), x0[keep[h:]])
         np.testing.assert_array_equal(half.x, full.x[h:])
         np.testing.assert_array_equal(half.status, full.status[h:])
+    with ResidentSLSQP(ctx, capacity=N) as res:              # the driver bench.py times: everything on the device
+        whole = res.solve(gather(keep), x0[keep])
+    np.testing.assert_array_equal(whole.x, full.x)
+    np.testing.assert_array_equal(whole.nit, full.nit)
+    np.testing.assert_array_equal(whole.status, full.status)
+    np.testing.assert_array_equal(whole.fun, full.fun)
+    assert (whole.n_eval, whole.n_eval_fd, whole.n_qp) == (full.n_eval, full.n_eval_fd, full.n_qp)
     sample = np.arange(0, len(keep), 997)
     with NativeBatchedSLSQP(ctx, threads=12, capacity=len(sample)) as host:
         want = host.solve(gather(keep[sample]), x0[keep[sample]])
