@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MPC_AMD_ABI_VERSION 7
+#define MPC_AMD_ABI_VERSION 8
 #define MPC_MAX_HORIZON 255
 
 typedef enum mpc_status {
@@ -159,6 +159,11 @@ int mpc_jacobian(mpc_ctx *ctx, int count, const double *q, double *J, void *stre
  * the action server reads from MoveIt to fill ee_pose (mpc_action_server.py:57-75).
  * q [N][6] -> pose [N][6] = [x,y,z,roll,pitch,yaw]. */
 int mpc_fk(mpc_ctx *ctx, int count, const double *q, double *pose, void *stream);
+
+/* Test hook, no counterpart in the reference (which calls numpy's sin/cos, DYN:97-128 through the DH chain):
+ * the evaluation kernels' own sin/cos routine applied to x [count] -> sn, cs [count], so that its accuracy over
+ * the joint range is tested directly.  Needs no parameters set. */
+int mpc_sincos_probe(mpc_ctx *ctx, int count, const double *x, double *sn, double *cs, void *stream);
 
 /* Batched platform predictor: replaces URMPC._predict_base_dynamic (MPC:606-651).
  * base [N][12] = [position, orientation, linear_velocity, angular_velocity] (base_observer.py:55-62),

@@ -308,6 +308,14 @@ class MpcContext:
         _ffi.check(self._ctx, self._lib.mpc_fk(self._ctx, N, qp, pose.data_ptr(), self._stream()))
         return pose
 
+    def sincos_probe(self, x: torch.Tensor):
+        """The evaluation kernels' own sin/cos on x [N] (test hook, include/mpc_amd.h: mpc_sincos_probe)."""
+        N = int(x.shape[0])
+        xp = self._chk(x, (N,), "x")
+        sn, cs = self._new(N), self._new(N)
+        _ffi.check(self._ctx, self._lib.mpc_sincos_probe(self._ctx, N, xp, sn.data_ptr(), cs.data_ptr(), self._stream()))
+        return sn, cs
+
     def predict_base_dynamic(self, base: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         """Batched ``_predict_base_dynamic`` (ur_mpc.py:606-651): base [N,12] -> [N,H,12]."""
         N = int(base.shape[0])

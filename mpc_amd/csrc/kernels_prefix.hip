@@ -706,6 +706,20 @@ hipError_t launch_prefix_rows(const mpc_params &P, const double *decay, const mp
                             : launch_mode<kCompact, 512, true>(P, A, g, grid, stream);
 }
 
+// Test hook: the kernel's own sin/cos on an array, so its accuracy is checked directly and not only
+// through the parity of whole evaluations (tests/test_gpu_parity.py::test_kernel_sincos_accuracy).
+__global__ void sincos_probe_kernel(int n, const double *__restrict__ x, double *__restrict__ sn, double *__restrict__ cs)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) sincos_small(x[i], &sn[i], &cs[i]);
+}
+
+hipError_t launch_sincos_probe(int n, const double *x, double *sn, double *cs, hipStream_t stream)
+{
+    hipLaunchKernelGGL(sincos_probe_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, n, x, sn, cs);
+    return hipGetLastError();
+}
+
 hipError_t launch_expand(const mpc_params &P, int count, const double *nz, double *jac, hipStream_t stream)
 {
     const int H = P.horizon;

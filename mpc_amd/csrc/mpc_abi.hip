@@ -355,6 +355,16 @@ int mpc_fk(mpc_ctx *ctx, int count, const double *q, double *pose, void *stream)
     return MPC_OK;
 }
 
+int mpc_sincos_probe(mpc_ctx *ctx, int count, const double *x, double *sn, double *cs, void *stream)
+{
+    if (!ctx) return MPC_ERR_INVALID_ARG;
+    if (count < 0 || (count > 0 && (!x || !sn || !cs))) return fail(ctx, MPC_ERR_INVALID_ARG, "bad count / NULL x, sn or cs");
+    if (count == 0) return MPC_OK;
+    MPC_HIP(ctx, hipSetDevice(ctx->device));
+    MPC_HIP(ctx, mpck::launch_sincos_probe(count, x, sn, cs, static_cast<hipStream_t>(stream)));
+    return MPC_OK;
+}
+
 int mpc_predict_base_dynamic(mpc_ctx *ctx, int count, const double *base, const double *dyn_host,
                              double *base_traj, void *stream)
 {

@@ -102,6 +102,7 @@ struct RowList {
     int bound = 0;
     int32_t *head = nullptr;          // device, zero on entry: work-queue head of the QP kernel (teams take requests in turn)
 };
+hipError_t launch_sincos_probe(int n, const double *x, double *sn, double *cs, hipStream_t stream);
 hipError_t launch_prefix_rows(const mpc_params &P, const double *decay, const mpc_scenarios &sc, const double *x, double *cost,
                               double *grad, double *con, double *nz, const RowList &rows, hipStream_t stream);
 hipError_t launch_qp_step_rows(int H, int teams, int rows, const RowList &list, const int32_t *flags, const double *lo,

@@ -415,3 +415,42 @@ def test_horizon_boundaries_of_the_kernel_variants(H):
     assert ctx.nz_supported() == (H <= 170)
     with pytest.raises(ValueError):
         params_for(256)
+
+
+def test_kernel_sincos_accuracy():
+    """The prefix kernel's own sin/cos (kernels_prefix.hip: sincos_small) against numpy's, which is what the
+    reference evaluates (ur20_dynamics.py:97-128 through the DH chain; yaw in ur_mpc.py:714-720).
+
+    Range: the joint limits are +-2 pi and a perturbed or predicted angle stays within a few radians of them, so
+    the dense part of the sample covers [-8, 8] rad including every multiple of pi/4 and pi/2 and their
+    neighbours (where the quadrant changes and where one of the two results passes through zero); a second
+    part goes out to +-1000 rad, far beyond any pose.  Bar: 2 ulp of the result's own magnitude inside
+    [-8, 8] and an absolute 1e-15 beyond (the two-constant reduction loses relative accuracy next to zeros
+    of sin/cos as |x| grows; the documented limit is ~1e5 rad), exact at 0, NaN for inf/NaN like the library."""
+    mp = params_for(1)
+    ctx = _ctx(mp, 1)
+    rng = np.random.default_rng(5)
+    grid = np.linspace(-8.0, 8.0, 400001)
+    k = np.arange(-12, 13)
+    special = np.concatenate([k * (np.pi / 4), np.nextafter(k * (np.pi / 4), 10.0), np.nextafter(k * (np.pi / 4), -10.0),
+                              k * (np.pi / 4) + 1e-9, k * (np.pi / 4) - 1e-9, [0.0, -0.0, 1e-300, 1e-8, -1e-8]])
+    near = np.concatenate([grid, special, rng.uniform(-8.0, 8.0, 200000)])
+    far = rng.uniform(-1000.0, 1000.0, 200000)
+    x = np.concatenate([near, far])
+    sn, cs = ctx.sincos_probe(torch.as_tensor(x, device="cuda"))
+    torch.cuda.synchronize()
+    sn, cs = sn.cpu().numpy(), cs.cpu().numpy()
+    rs, rc = np.sin(x), np.cos(x)
+    n = len(near)
+    for got, ref in ((sn, rs), (cs, rc)):
+        err = np.abs(got[:n] - ref[:n])
+        tol = 2.0 * np.spacing(np.abs(ref[:n])) + 1e-300
+        # next to a zero of the function the result is ~1e-16..1e-9 and the reduction's absolute error
+        # (~|k| * 2^-110) is what matters, not ulps of that tiny result
+        assert np.all((err <= tol) | (err <= 4e-32 + 1e-16 * np.abs(ref[:n]))), float((err / np.spacing(np.abs(ref[:n]))).max())
+        assert np.abs(got[n:] - ref[n:]).max() <= 1e-15
+    assert np.all(sn[x == 0.0] == 0.0) and np.all(cs[x == 0.0] == 1.0)
+    bad = torch.tensor([float("inf"), float("-inf"), float("nan")], device="cuda", dtype=torch.float64)
+    sb, cb = ctx.sincos_probe(bad)
+    assert torch.isnan(sb).all() and torch.isnan(cb).all()
+    ctx.close()
