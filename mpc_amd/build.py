@@ -76,7 +76,7 @@ def build_slsqp(force: bool = False, verbose: bool = False) -> str:
     srcs = [os.path.join(CSRC, u) for u in _SLSQP_UNITS]
     deps = srcs + [os.path.join(CSRC, "slsqp_core.h"), os.path.join(CSRC, "slsqp_body.inc"),
                    os.path.join(_ROOT, "include", "mpc_slsqp.h")]
-    spmd = [os.path.join(CSRC, "lsq_spmd_host.cpp"), os.path.join(CSRC, "lsq_spmd.hpp")]
+    spmd = [os.path.join(CSRC, "lsq_spmd_host.cpp"), os.path.join(CSRC, "lsq_spmd.hpp"), os.path.join(CSRC, "lsq_wave.hpp")]
     if force or _stale(SLSQP_LIB_PATH, deps + spmd):
         objdir = os.path.join(_HERE, "build")
         os.makedirs(objdir, exist_ok=True)

@@ -16,6 +16,7 @@
 namespace {
 
 struct HipTeam {
+    [[maybe_unused]] static constexpr bool kWave = true;       // whole wavefronts, thread t in wavefront t / 64: lsq_wave.hpp applies
     __device__ int tid() const { return (int)threadIdx.x; }
     __device__ int size() const { return (int)blockDim.x; }
     __device__ void sync() const { __syncthreads(); }

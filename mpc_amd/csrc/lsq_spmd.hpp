@@ -56,9 +56,12 @@ __device__ unsigned long long mpc_qp_prof[32];
 #define QP_MARK_START(T) do {} while (0)
 #endif
 
+#include "lsq_wave.hpp"
+
 namespace lsqspmd {
 
 struct SerialTeam {
+    static constexpr bool kWave = false;      // not a team of whole wavefronts: lsq_wave.hpp is never used
     SPMD_HD int tid() const { return 0; }
     SPMD_HD int size() const { return 1; }
     SPMD_HD void sync() const {}
@@ -777,17 +780,34 @@ SPMD_HD int lsq(const Team &T, const Work &W, int H, const double *g, const doub
     // ---- f: solve e^T f = g by forward substitution, column-oriented: once f(k) is known every later row adds its
     //      term e(k, i) f(k), which it does in the order k = 0, 1, ... of the serial dot product; the thread that
     //      owns row k + 1 (always thread 0) finishes f(k + 1) in the same sweep.  Then negate.
-    if (T.tid() == 0) W.ff[0] = (W.xs[0] - 0.0) / W.E[0];
-    T.sync();
-    for (int k = 0; k + 1 < n; ++k) {
-        const double fk = W.ff[k];
-        const double *ek = W.E + EO(k) - k;            // ek[i] = e(k, i)
-        PAR_FOR(T, i, k + 1, n) {
-            const double t = W.acc[i] + ek[i] * fk;
-            W.acc[i] = t;
-            if (i == k + 1) W.ff[i] = (W.xs[i] - t) / W.E[EO(i)];
+    bool in_registers = false;
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (Team::kWave) {
+        if (n <= lsqwave::kMaxN) {                          // the team's first wavefront, sums in registers (lsq_wave.hpp)
+            if (T.tid() < 64) {
+                const bool ok = lsqwave::forward_substitute(W.E, W.xs, W.ff, W.acc, n);
+                for (int i = T.tid(); i < n; i += 64) W.acc[i] = 0.0;      // it was scratch there; the team code adds into it
+                if (T.tid() == 0) W.isc[14] = ok ? 1 : 0;
+            }
+            T.sync();
+            in_registers = W.isc[14] != 0;                  // false: an operand out of the routine's range, ff not valid
+            T.sync();
         }
+    }
+#endif
+    if (!in_registers) {
+        if (T.tid() == 0) W.ff[0] = (W.xs[0] - 0.0) / W.E[0];
         T.sync();
+        for (int k = 0; k + 1 < n; ++k) {
+            const double fk = W.ff[k];
+            const double *ek = W.E + EO(k) - k;            // ek[i] = e(k, i)
+            PAR_FOR(T, i, k + 1, n) {
+                const double t = W.acc[i] + ek[i] * fk;
+                W.acc[i] = t;
+                if (i == k + 1) W.ff[i] = (W.xs[i] - t) / W.E[EO(i)];
+            }
+            T.sync();
+        }
     }
     PAR_FOR(T, i, 0, n) W.ff[i] = -1.0 * W.ff[i];
     T.sync();
@@ -913,7 +933,20 @@ SPMD_HD int lsq(const Team &T, const Work &W, int H, const double *g, const doub
     // first wavefront alone (up to 64 threads form the products, its first thread adds them up): what one wavefront
     // writes to LDS it reads back in program order, so no workgroup barrier separates the 2n steps; the other
     // wavefronts wait at the one barrier after the loop.
-    {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (Team::kWave) {
+        if (in_registers) {                                // lsq_wave.hpp: the same chain at ~8 cycles per term
+            if (T.tid() < 64) {
+                const bool ok = lsqwave::back_substitute(W.E, W.xs, W.acc, n);
+                if (T.tid() == 0) W.isc[14] = ok ? 1 : 0;
+            }
+            T.sync();
+            in_registers = W.isc[14] != 0;                  // false: xs is as it was, the team code below runs
+            T.sync();
+        }
+    }
+#endif
+    if (!in_registers) {
         const int wl = T.size() < 64 ? T.size() : 64;
         if (T.tid() < wl) {
             for (int i = n - 1; i >= 0; --i) {
@@ -980,9 +1013,19 @@ SPMD_HD void ldl(const Team &T, const Work &W, int n, double *a, double *z, doub
     double *alp = W.xn, *bet = W.xn + n, *gam = W.xn + 2 * n, *tpv = W.xn + 3 * n;
 #define DIAG(i) ((i) * n - ((i) * ((i) - 1)) / 2)
     // ---- A
-    PAR_FOR(T, i, 0, n) vv[i] = z[i];
-    T.sync();
-    {
+    bool in_registers = false;
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (Team::kWave) {
+        if (n <= lsqwave::kMaxN) {                          // the team's first wavefront, v in registers (lsq_wave.hpp)
+            in_registers = true;
+            if (T.tid() < 64) lsqwave::unit_lower_solve(a, z, vv, n);
+            T.sync();
+        }
+    }
+#endif
+    if (!in_registers) {
+        PAR_FOR(T, i, 0, n) vv[i] = z[i];
+        T.sync();
         int ij = 1;
         for (int i = 1; i < n; ++i) {
             const double v = vv[i - 1];
