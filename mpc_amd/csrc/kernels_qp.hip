@@ -9,16 +9,30 @@
 // Teams of 256 threads, two per CU (LDS), hence two waves per SIMD and 256 VGPRs per wave: the row transform keeps
 // its 2 x 12 accumulators, the row's earlier entries and a row of e in registers without spilling (with 512-thread
 // teams, 128 VGPRs per wave, it spilled ~140 registers and whole solves were 8 % slower).
+#ifndef MPC_QP_ROT
+#define MPC_QP_ROT 0
+#endif
 #ifndef MPC_QP_WAVES
 #define MPC_QP_WAVES 2
 #endif
 
 namespace {
 
+template <bool kLds>
 struct HipTeam {
+    static constexpr bool kLdsPool = kLds;       // the small pool (W.E, W.ff, ...) is LDS
     [[maybe_unused]] static constexpr bool kWave = true;       // whole wavefronts, thread t in wavefront t / 64: lsq_wave.hpp applies
     __device__ int tid() const { return (int)threadIdx.x; }
     __device__ int size() const { return (int)blockDim.x; }
+    // By how many wavefronts this team's share-out of uneven work is turned (the row transform's first wavefronts carry
+    // the long rows): the two teams of a CU should not both load the same SIMDs.
+#if MPC_QP_ROT == 1
+    __device__ int turn() const { return (blockIdx.x >= gridDim.x / 2) ? 2 : 0; }
+#elif MPC_QP_ROT == 2
+    __device__ int turn() const { return (blockIdx.x & 1u) ? 2 : 0; }
+#else
+    __device__ int turn() const { return 0; }
+#endif
     __device__ void sync() const { __syncthreads(); }
     // orders the LDS traffic of ONE wavefront (threads 0..63 of the team): its earlier writes are done before its later
     // reads; no other wavefront is waited for
@@ -57,7 +71,7 @@ qp_kernel(int H, int count, const double *__restrict__ l, const double *__restri
     const int n = 6 * H, m = 12 * (H + 1), mg = m + 2 * n, nzc = 6 * H + 3 * H * (H + 1);
     const int ldl = (n + 1) * n / 2 + 1;
     const lsqspmd::Work W = team_work<kLds>(work, iwork, wd, wi, n, m);
-    const HipTeam T;
+    const HipTeam<kLds> T;
     for (int p = (int)blockIdx.x; p < count; p += (int)gridDim.x) {
         const double *lp = l + (size_t)p * ldl;
         PAR_FOR(T, e, 0, ldl) W.E[e] = lp[e];
@@ -89,7 +103,7 @@ qp_step_kernel(int H, int count, int rows, const int32_t *__restrict__ index, co
     const int n = 6 * H, m = 12 * (H + 1), mg = m + 2 * n, nzc = 6 * H + 3 * H * (H + 1);
     const int ldl = (n + 1) * n / 2 + 1;
     const lsqspmd::Work W = team_work<kLds>(work, iwork, wd, wi, n, m);
-    const HipTeam T;
+    const HipTeam<kLds> T;
     if (kRows) count = *count_dev;
     // kRows: the teams take requests from a shared queue (QPs differ a lot in cost: a fixed share per team would leave
     // most teams waiting for the slowest); every team leaves the loop at its first k >= count.

@@ -21,6 +21,7 @@
 
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #define SPMD_HD __host__ __device__
 #else
 #define SPMD_HD
@@ -62,8 +63,10 @@ namespace lsqspmd {
 
 struct SerialTeam {
     static constexpr bool kWave = false;      // not a team of whole wavefronts: lsq_wave.hpp is never used
+    static constexpr bool kLdsPool = false;
     SPMD_HD int tid() const { return 0; }
     SPMD_HD int size() const { return 1; }
+    SPMD_HD int turn() const { return 0; }
     SPMD_HD void sync() const {}
     SPMD_HD void wave_sync() const {}
 };
@@ -557,22 +560,154 @@ SPMD_HD inline RowDesc describe_row(int H, int i, const double *cvals, const dou
 }
 
 #if defined(__HIP_DEVICE_COMPILE__)
-// the double that lane `lane` of this wavefront holds in v, for every lane, through the scalar unit (two v_readlane):
-// how a wavefront shares entries of the triangle that it loaded one per lane, instead of every lane reading every entry
-// from LDS itself (64 lanes reading one address still cost the LDS pipe 64 lanes' worth of bandwidth)
-__device__ __forceinline__ double lane_bcast(double v, int lane)
+// The double that lane L of each row of 16 lanes holds in v, for every lane of that row: one v_mov_b64 with the DPP
+// row broadcast.  (Through the scalar unit - two v_readlane - the multiply that uses it waits ~20 cycles longer.)
+template <int L>
+__device__ __forceinline__ double row_bcast(double v)
 {
-    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
-    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
-    return __hiloint2double(hi, lo);
+    return __builtin_amdgcn_update_dpp(0.0, v, 0x150 + L, 0xf, 0xf, true);
+}
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F &&f)
+{
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+// transform_cols for a whole wavefront (every lane is here, control flow is uniform; a lane's own rows are rows[], row i
+// of the result at out[i + j mg]: one scalar base per column and one lane offset per row address every entry).
+// Entries of e are not read by every lane from LDS (64 lanes reading one address cost the LDS pipe 64 lanes of
+// bandwidth, and one LDS instruction costs a lone wavefront ~30 cycles of issue): the 6 x NC block that six steps need
+// is loaded once, entry t = 16 j + lane % 16 into register j of every row of 16 lanes, and each entry reaches the
+// multiplies by row_bcast.  The same for the triangle inside the column block and for f.  The row's earlier entries
+// (global memory) and the next block of e are requested one block ahead.
+// A lane whose rows start later than the wavefront's first block (kb_lo) walks the earlier blocks with its rows'
+// stored entries, (0 - 0) / e(j, j): what the serial text does with a row's leading zeros.
+template <int NB, int R>
+__device__ __forceinline__ void transform_cols_wave(const Work &W, int n, int mg, int H, const double *nz, double *out,
+                                                    const int *rows, int jj0, const RowDesc *d, double *th, int kb_lo, bool store)
+{
+    constexpr int NC = 6 * NB, NE = 6 * NC, NR = (NE + 15) / 16, NT = NC * (NC + 1) / 2, NTR = (NT + 15) / 16;
+    const int jb = 6 * jj0, lane16 = (int)(threadIdx.x & 15u);
+    unsigned rowb[R];                                      // a row's place in a column, in bytes: the lane's 32-bit offset
+    SPMD_UNROLL
+    for (int r = 0; r < R; ++r) rowb[r] = 8u * (unsigned)rows[r];
+#define EO(r) ((r) * n - ((r) * ((r) - 1)) / 2)
+    double acc[R][NC];
+    SPMD_UNROLL
+    for (int r = 0; r < R; ++r) {
+        SPMD_UNROLL
+        for (int c = 0; c < NC; ++c) acc[r][c] = 0.0;
+    }
+    if (kb_lo < jj0) {
+        // entry t of block kb is e(6 kb + t / NC, jb + t % NC), at E[f(k) + jb + t % NC] with k = 6 kb + t / NC and
+        // f(k) = k (n - 1) - k (k - 1) / 2; from one block to the next f grows by 6 (n - 1) - 6 k - 15
+        int off[NR], step[NR];
+        SPMD_UNROLL
+        for (int j = 0; j < NR; ++j) {
+            const int t = 16 * j + lane16 < NE ? 16 * j + lane16 : 0;
+            const int k = 6 * kb_lo + t / NC;
+            off[j] = k * (n - 1) - (k * (k - 1)) / 2 + jb + t % NC;
+            step[j] = 6 * (n - 1) - 6 * k - 15;
+        }
+        // Block kb + 1 (its entries of e, the rows' own earlier entries from global memory) is requested before block
+        // kb is used; two register sets take turns, the loop is unrolled by two so that neither is ever copied.
+        double ea[NR], eb[NR], ga[R][6], gb[R][6];
+        auto fetch = [&](int kb, double (&e)[NR], double (&g)[R][6]) {
+            SPMD_UNROLL
+            for (int j = 0; j < NR; ++j) e[j] = W.E[off[j]];
+            SPMD_UNROLL
+            for (int r = 0; r < R; ++r) {
+                SPMD_UNROLL
+                for (int q = 0; q < 6; ++q) g[r][q] = *(const double *)((const char *)(out + (size_t)(6 * kb + q) * mg) + rowb[r]);
+            }
+            SPMD_UNROLL
+            for (int j = 0; j < NR; ++j) { off[j] += step[j]; step[j] -= 36; }
+        };
+        auto block = [&](int kb, const double (&e)[NR], const double (&g)[R][6], double (&en)[NR], double (&gn)[R][6]) {
+            if (kb + 1 < jj0) fetch(kb + 1, en, gn);
+            // One entry at a time, in this order: each entry's sums pass through an empty volatile asm, which instruction
+            // selection and the scheduler keep in place (left alone they issue all the broadcasts of a block first, and
+            // their 72 results spill; a scheduling barrier alone comes too late, the order is chosen before it acts).
+            static_for<0, NE>([&](auto T) {
+                constexpr int t = decltype(T)::value, q = t / NC, c = t % NC;
+                const double b = row_bcast<t % 16>(e[t / 16]);
+                SPMD_UNROLL
+                for (int r = 0; r < R; ++r) {
+                    acc[r][c] = acc[r][c] + g[r][q] * b;
+                    asm volatile("" : "+v"(acc[r][c]));
+                }
+            });
+        };
+        fetch(kb_lo, ea, ga);
+        int kb = kb_lo;
+        for (; kb + 1 < jj0; kb += 2) {
+            block(kb, ea, ga, eb, gb);
+            block(kb + 1, eb, gb, ea, ga);
+        }
+        if (kb < jj0) block(kb, ea, ga, eb, gb);
+    }
+    // the triangle inside the column block, entry u = c (c + 1) / 2 + c2 = e(jb + c2, jb + c), c2 <= c, and f
+    double tri[NTR];
+    SPMD_UNROLL
+    for (int j = 0; j < NTR; ++j) {
+        const int u = 16 * j + lane16 < NT ? 16 * j + lane16 : 0;
+        int c = 0;
+        SPMD_UNROLL
+        for (int cc = 1; cc < NC; ++cc) c += u >= (cc * (cc + 1)) / 2 ? 1 : 0;
+        const int c2 = u - (c * (c + 1)) / 2;
+        tri[j] = W.E[EO(jb + c2) + (c - c2)];
+    }
+    const double fv = W.ff[jb + (lane16 < NC ? lane16 : 0)];
+    double val[R][NB];
+    SPMD_UNROLL
+    for (int r = 0; r < R; ++r) {
+        SPMD_UNROLL
+        for (int b = 0; b < NB; ++b) {
+            const int jj = jj0 + b;
+            double v = 0.0;
+            if (jj >= d[r].first && jj <= d[r].last) {
+                if (d[r].kind == 1) v = nz[6 * H + 6 * (jj * H - (jj * (jj - 1)) / 2 - jj - 1 + d[r].kk) + d[r].a];
+                else if (d[r].kind == 2) v = nz[6 * jj + d[r].a];
+                else v = (d[r].kind == 3) ? 1.0 : -1.0;
+            }
+            val[r][b] = v;
+        }
+    }
+    static_for<0, NC>([&](auto C) {
+        constexpr int c = decltype(C)::value;
+        double t[R];
+        SPMD_UNROLL
+        for (int r = 0; r < R; ++r) t[r] = acc[r][c];
+        static_for<0, c>([&](auto C2) {
+            constexpr int c2 = decltype(C2)::value, u = (c * (c + 1)) / 2 + c2;
+            const double e = row_bcast<u % 16>(tri[u / 16]);
+            SPMD_UNROLL
+            for (int r = 0; r < R; ++r) {
+                t[r] = t[r] + acc[r][c2] * e;                                 // acc[r][c2] holds the new g(i_r, jb + c2)
+                asm volatile("" : "+v"(t[r]));
+            }
+        });
+        constexpr int ud = (c * (c + 1)) / 2 + c;
+        const double diag = row_bcast<ud % 16>(tri[ud / 16]), fj = row_bcast<c>(fv);
+        SPMD_UNROLL
+        for (int r = 0; r < R; ++r) {
+            const double orig = (c % 6 == d[r].a) ? val[r][c / 6] : 0.0;
+            const double gn = (orig - t[r]) / diag;
+            acc[r][c] = gn;
+            if (store) *(double *)((char *)(out + (size_t)(jb + c) * mg) + rowb[r]) = gn;
+            th[r] = th[r] + gn * fj;
+        }
+    });
+#undef EO
 }
 #endif
 
-// COOP: every lane of the wavefront is here together (device only; the caller guarantees it), so the rows of e are
-// loaded cooperatively, one entry per lane, and broadcast with lane_bcast.  kb_lo <= every lane's first_any.
-template <int NB, int R, bool COOP>
+template <int NB, int R>
 SPMD_HD inline void transform_cols(const Work &W, int n, int mg, int H, const double *nz, double *const *dst, int jj0,
-                                   const RowDesc *d, int first_any, double *th, int kb_lo = 0, bool store = true)
+                                   const RowDesc *d, int first_any, double *th, bool store = true)
 {
     constexpr int NC = 6 * NB;
     const int jb = 6 * jj0;
@@ -583,54 +718,6 @@ SPMD_HD inline void transform_cols(const Work &W, int n, int mg, int H, const do
         SPMD_UNROLL
         for (int c = 0; c < NC; ++c) acc[r][c] = 0.0;
     }
-#if defined(__HIP_DEVICE_COMPILE__)
-    if constexpr (COOP) {
-        // entry number t of the 6 x NC block of e that six steps k = 6 kb + q need is e(6 kb + t / NC, jb + t % NC):
-        // lane L holds entries L and L + 64
-        static_assert(6 * NC <= 128, "two entries per lane cover the block");
-        const int lane = (int)(threadIdx.x & 63u);
-        const int qa = lane / NC, ca = lane - qa * NC;
-        const int tb = lane + 64, qb = tb / NC, cb = tb - qb * NC;
-        const bool has_a = lane < 6 * NC, has_b = tb < 6 * NC;
-        for (int kb = kb_lo; kb < jj0; ++kb) {
-            const int ka = 6 * kb + qa, kbb = 6 * kb + qb;
-            const double va = has_a ? W.E[EO(ka) + (jb - ka) + ca] : 0.0;
-            const double vb = has_b ? W.E[EO(kbb) + (jb - kbb) + cb] : 0.0;
-            if (kb >= first_any) {
-                double gk[R][6];
-                SPMD_UNROLL
-                for (int r = 0; r < R; ++r) {
-                    SPMD_UNROLL
-                    for (int q = 0; q < 6; ++q) gk[r][q] = dst[r][(size_t)(6 * kb + q) * mg];
-                }
-                // products first, six columns at a time, then the additions: an addition right behind its own product
-                // would wait out the multiplier's latency every time
-                SPMD_UNROLL
-                for (int q = 0; q < 6; ++q) {
-                    SPMD_UNROLL
-                    for (int c6 = 0; c6 < NC; c6 += 6) {
-                        double pr[R][6];
-                        SPMD_UNROLL
-                        for (int c = 0; c < 6; ++c) {
-                            const int t = q * NC + c6 + c;
-                            const double e = t < 64 ? lane_bcast(va, t) : lane_bcast(vb, t - 64);
-                            SPMD_UNROLL
-                            for (int r = 0; r < R; ++r) pr[r][c] = gk[r][q] * e;
-                        }
-#if defined(__HIP_DEVICE_COMPILE__)
-                        __builtin_amdgcn_sched_barrier(0);
-#endif
-                        SPMD_UNROLL
-                        for (int c = 0; c < 6; ++c) {
-                            SPMD_UNROLL
-                            for (int r = 0; r < R; ++r) acc[r][c6 + c] = acc[r][c6 + c] + pr[r][c];
-                        }
-                    }
-                }
-            }
-        }
-    } else
-#endif
     {
         const double *er = W.E + jb;                       // er[c] = e(k, jb + c), advanced row by row
         for (int kb = 0; kb < jj0; ++kb) {
@@ -697,9 +784,27 @@ SPMD_HD inline void transform_cols(const Work &W, int n, int mg, int H, const do
 #undef EO
 }
 
+// Row number p of [g h] in order of the work its transform takes: the 6H position rows of states 1 .. H (nonzeros from
+// block 0 on), then for f = 0 .. H - 1 the rows that begin at block f (the velocity rows of state f + 1, the lower and
+// the upper bound rows of its six variables), last the 12 rows of state 0 (no variable enters them).
+SPMD_HD inline int work_order(int H, int p)
+{
+    const int n = 6 * H, m = 12 * (H + 1);
+    if (p < n) return 12 * (p / 6 + 1) + p % 6;
+    const int q = p - n;
+    if (q < 18 * H) {
+        const int f = q / 18, r = q % 18;
+        if (r < 6) return 12 * (f + 1) + 6 + r;
+        if (r < 12) return m + 6 * f + (r - 6);
+        return m + n + 6 * f + (r - 12);
+    }
+    return q - 18 * H;
+}
+
 template <int R, bool COOP = false>
 SPMD_HD inline void transform_rows(const Work &W, int H, const int *rows, const double *cvals, const double *nz,
-                                   const double *lo, const double *hi, double *const *dst, bool store = true)
+                                   const double *lo, const double *hi, double *const *dst, bool store = true,
+                                   double *base = nullptr)      // COOP: dst[r] = base + rows[r], base the same in every lane
 {
     const int n = 6 * H, mg = 12 * (H + 1) + 2 * n;
     RowDesc d[R];
@@ -719,6 +824,7 @@ SPMD_HD inline void transform_rows(const Work &W, int H, const int *rows, const 
             const int other = __shfl_xor(skip_to, off);
             skip_to = other < skip_to ? other : skip_to;
         }
+        skip_to = __builtin_amdgcn_readfirstlane(skip_to);   // the same in every lane: say so, the loops over blocks are scalar
     }
 #endif
     int jj = 0;
@@ -733,15 +839,73 @@ SPMD_HD inline void transform_rows(const Work &W, int H, const int *rows, const 
                 }
             }
         } else {
-            transform_cols<MPC_QP_NB, R, COOP>(W, n, mg, H, nz, dst, jj, d, first_any, th, skip_to, store);
+#if defined(__HIP_DEVICE_COMPILE__)
+            if constexpr (COOP) transform_cols_wave<MPC_QP_NB, R>(W, n, mg, H, nz, base, rows, jj, d, th, skip_to, store);
+            else
+#endif
+                transform_cols<MPC_QP_NB, R>(W, n, mg, H, nz, dst, jj, d, first_any, th, store);
         }
     }
-    for (; jj < H; ++jj) transform_cols<1, R, COOP>(W, n, mg, H, nz, dst, jj, d, first_any, th, skip_to < jj ? skip_to : jj, store);
+    for (; jj < H; ++jj) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        if constexpr (COOP) transform_cols_wave<1, R>(W, n, mg, H, nz, base, rows, jj, d, th, skip_to < jj ? skip_to : jj, store);
+        else
+#endif
+            transform_cols<1, R>(W, n, mg, H, nz, dst, jj, d, first_any, th, store);
+    }
     if (store) {
         SPMD_UNROLL
         for (int r = 0; r < R; ++r) dst[r][(size_t)n * mg] = d[r].hval - th[r];
     }
 }
+
+#if defined(__HIP_DEVICE_COMPILE__)
+// transform_rows for a whole wavefront as a function of its own, not inlined: the kernel around it keeps ~140 vector
+// registers alive through every phase, and inlined the transform has no room left to request a row's earlier entries
+// one block ahead.  Arguments of a device function arrive in vector registers, uniform or not: the scalar ones are
+// made scalar again (v_readfirstlane), and the two pool pointers come as LDS offsets when the pool is LDS, so that the
+// reads of e stay LDS instructions.
+__device__ __forceinline__ int scalar_again(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ unsigned long long scalar_bits(const void *p)
+{
+    const unsigned long long v = (unsigned long long)p;
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
+    return ((unsigned long long)hi << 32) | lo;
+}
+// ... and a pointer to global memory is said to be one: a pointer that arrives as an argument is generic otherwise, and a
+// generic load needs its whole address in vector registers, where a global one takes a scalar base and a lane offset
+__device__ __forceinline__ double *global_again(const double *p)
+{
+    typedef __attribute__((address_space(1))) double GlobalDouble;
+    return (double *)(GlobalDouble *)scalar_bits(p);
+}
+template <int R, bool LDS>
+__device__ __attribute__((noinline)) void transform_rows_call(const double *E, const double *ff, unsigned e_lds, unsigned ff_lds,
+                                                              double *AT, int H, const double *cvals, const double *nz,
+                                                              const double *lo, const double *hi, int row0, int row1, int store)
+{
+    static_assert(R == 2, "two rows per lane");
+    Work W{};
+    if constexpr (LDS) {
+        typedef __attribute__((address_space(3))) double LdsDouble;
+        W.E = (double *)(LdsDouble *)(unsigned long long)scalar_again((int)e_lds);
+        W.ff = (double *)(LdsDouble *)(unsigned long long)scalar_again((int)ff_lds);
+    } else {
+        W.E = global_again(E);
+        W.ff = global_again(ff);
+    }
+    AT = global_again(AT);
+    cvals = global_again(cvals);
+    nz = global_again(nz);
+    lo = global_again(lo);
+    hi = global_again(hi);
+    W.AT = AT;
+    const int rows[2] = {row0, row1};
+    double *const dst[2] = {AT + row0, AT + row1};
+    transform_rows<2, true>(W, scalar_again(H), rows, cvals, nz, lo, hi, dst, store != 0, AT);
+}
+#endif
 
 // Kraft's LSQ for the MPC shape.  W.E holds the packed LDL' factor l on entry ((n+1)n/2 + 1 entries; it is
 // overwritten), g: gradient, cvals: c(x), nz: structured dc/dx, lo / hi: bounds on the step (xl - x, xu - x).
@@ -846,25 +1010,39 @@ SPMD_HD int lsq(const Team &T, const Work &W, int H, const double *g, const doub
     T.sync();
     if (!W.isc[8]) return 5;
     QP_MARK(T, 2);   // QR rows
-    // ---- [g h] <- [g e^-1, h - g f], one row per index, into the matrix NNLS works on
-    //      (MPC_QP_ROWS rows per index, spread evenly over the matrix: they share the reads of e; m + 2n = 12(2H + 1)
-    //      is a multiple of 2, 3 and 4)
-    //      Whole wavefronts walk the loop together (a lane beyond the last row repeats that row without storing), so
-    //      that on the device a wavefront can load the rows of e once for all its lanes.
+    // ---- [g h] <- [g e^-1, h - g f], MPC_QP_ROWS rows per index (they share the reads of e), into the matrix NNLS
+    //      works on.  Whole wavefronts walk the loop together (a lane beyond the last row repeats a row without
+    //      storing), so that on the device a wavefront loads the entries of e once for all its lanes; and the rows are
+    //      dealt out in the order of work_order: a row's work begins at its first nonzero block, and a wavefront walks
+    //      from the earliest block any of its rows needs, so rows that begin late share wavefronts
+    //      (m + 2n = 12 (2H + 1) is a multiple of 2, 3 and 4).
     {
         const int per = mg / MPC_QP_ROWS, width = T.size() < 64 ? T.size() : 64;
-        for (int base = (T.tid() / width) * width; base < per; base += T.size()) {
+        const int waves = T.size() / width;
+        for (int base = ((T.tid() / width + T.turn()) % waves) * width; base < per; base += T.size()) {
             const int want = base + T.tid() % width;
             const bool mine = want < per;
             const int i = mine ? want : per - 1;
+            const int wide = per - base < width ? per - base : width;        // indices of this wavefront
             int rows[MPC_QP_ROWS];
             double *dst[MPC_QP_ROWS];
             SPMD_UNROLL
             for (int r = 0; r < MPC_QP_ROWS; ++r) {
-                rows[r] = i + r * (mg / MPC_QP_ROWS);
+                rows[r] = work_order(H, base * MPC_QP_ROWS + r * wide + (i - base));
                 dst[r] = W.AT + rows[r];
             }
-            transform_rows<MPC_QP_ROWS, true>(W, H, rows, cvals, nz, lo, hi, dst, mine);
+#if defined(__HIP_DEVICE_COMPILE__)
+            if constexpr (Team::kWave && MPC_QP_ROWS == 2) {
+                typedef __attribute__((address_space(3))) double LdsDouble;
+                unsigned e_lds = 0, ff_lds = 0;
+                if constexpr (Team::kLdsPool) {
+                    e_lds = (unsigned)(unsigned long long)(LdsDouble *)W.E;
+                    ff_lds = (unsigned)(unsigned long long)(LdsDouble *)W.ff;
+                }
+                transform_rows_call<2, Team::kLdsPool>(W.E, W.ff, e_lds, ff_lds, W.AT, H, cvals, nz, lo, hi, rows[0], rows[1], mine ? 1 : 0);
+            } else
+#endif
+                transform_rows<MPC_QP_ROWS, true>(W, H, rows, cvals, nz, lo, hi, dst, mine, W.AT);
         }
     }
     QP_MARK(T, 3);   // transform
