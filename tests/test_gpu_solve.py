@@ -432,6 +432,17 @@ def test_qp_subproblem_on_the_device_is_bit_identical_to_the_host_core(H, N):
         inp = None
         if n_ == n and nl == ldl:
             inp = (arr(l, ldl), arr(g, n), arr(b, m_), arr(a, (n + 1) * la)[scatter], arr(xl, n), arr(xu, n))
+            if len(rec) < 4 * N:
+                # The same problem with operands far outside the range in which the kernel's single-wavefront
+                # recurrences (csrc/lsq_wave.hpp) split their divisions: a tiny gradient, a zero gradient (forward
+                # substitution declines), huge constraint values (back substitution declines, having restored its
+                # input).  The team code must take over with the same bits as ever.
+                for gs, bs in ((2.0 ** -460, 1.0), (0.0, 1.0), (1.0, 2.0 ** 450)):
+                    g2, b2 = inp[1] * gs, inp[2] * bs
+                    x2, y2, md2 = np.zeros(n), np.zeros(m_ + 2 * n + 2), ctypes.c_int(0)
+                    builtin(m_, meq, n_, nl, la, l, g2.ctypes.data_as(dp), a, b2.ctypes.data_as(dp), xl, xu,
+                            x2.ctypes.data_as(dp), y2.ctypes.data_as(dp), w, jw, ctypes.byref(md2))
+                    rec.append((inp[0], g2, b2, inp[3], inp[4], inp[5], x2.copy(), y2[:m_].copy(), md2.value))
         builtin(m_, meq, n_, nl, la, l, g, a, b, xl, xu, x, y, w, jw, mode)
         if inp is not None:
             rec.append(inp + (arr(x, n), arr(y, m_), mode[0]))
@@ -467,9 +478,12 @@ def test_qp_subproblem_on_the_device_is_bit_identical_to_the_host_core(H, N):
     up = lambda k: torch.as_tensor(np.stack([r[k] for r in rec])).to(ctx.device)
     s, y, mode = ctx.qp_solve(up(0), up(1), up(2), up(3), up(4), up(5))
     torch.cuda.synchronize()
-    np.testing.assert_array_equal(mode.cpu().numpy(), np.array([r[8] for r in rec]))
-    np.testing.assert_array_equal(s.cpu().numpy(), np.stack([r[6] for r in rec]))
-    np.testing.assert_array_equal(y.cpu().numpy()[:, :m], np.stack([r[7] for r in rec]))
+    want_mode = np.array([r[8] for r in rec])
+    np.testing.assert_array_equal(mode.cpu().numpy(), want_mode)
+    ok = want_mode == 1                                     # (a failed QP leaves step and multipliers undefined)
+    assert ok.sum() >= N
+    np.testing.assert_array_equal(s.cpu().numpy()[ok], np.stack([r[6] for r in rec])[ok])
+    np.testing.assert_array_equal(y.cpu().numpy()[ok][:, :m], np.stack([r[7] for r in rec])[ok])
 
 
 def test_device_qp_driver_equals_host_driver():
