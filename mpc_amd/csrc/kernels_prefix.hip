@@ -36,6 +36,7 @@ struct PrefixArgs {
     double *jac;
     double *compact;  // MODE 2: per scenario [6H velocity quotients][3H(H+1) position quotients]
     int cstride;      // doubles per scenario in `compact`
+    int tmajor;       // MODE 2, internal workspace only: quotients laid out [iteration][phase-2 lane] (coalesced stores)
     int S;            // scenarios per workgroup
     int items;        // phase-2 lanes per scenario = 6 * ceil(H/2)
     // ROWS form (device-resident solves): evaluate rows list[0 .. *count_dev) of every array in place
@@ -477,11 +478,18 @@ __global__ __launch_bounds__(MAXT) void prefix_kernel(const mpc_params P, const 
                 if (k == j) S2[Y.jvel + var] = jv;
             } else if (A.jac != nullptr) {
                 double *cz = A.compact + row(ls2) * A.cstride;
-                cz[6 * H + 6 * (tri_j + k + 1) + a] = jp;
-                if (k == j) cz[var] = jv;
+                if (A.tmajor) {
+                    cz[step * A.items + it] = jp;   // one contiguous run per wavefront and iteration
+                } else {
+                    cz[6 * H + 6 * (tri_j + k + 1) + a] = jp;
+                    if (k == j) cz[var] = jv;
+                }
             }
             k = k + 1;
         } else {
+            if (MODE == kCompact && A.jac != nullptr && A.tmajor)   // the terminal iteration's slot carries the velocity quotient
+                A.compact[row(ls2) * A.cstride + step * A.items + it] =
+                    quot((lim - fabs(xv)) - (lim - fabs(x0v)), dx, rdx);
             if (A.grad != nullptr) A.grad[row(ls2) * n + var] = quot(acc - f0, dx, rdx);  // NUMDIFF:619
             pert = pert + 1;
             if (pert < npert) need_init = true; else active = false;
@@ -547,49 +555,114 @@ __global__ __launch_bounds__(MAXT) void prefix_kernel(const mpc_params P, const 
 }
 
 // kCompact's second half: one workgroup per (scenario, step jj) writes the six dense columns of that
-// step (12(H+1) rows each) from the quotients kCompact left in the workspace.  Same row ownership
-// as phase 3 of the fused kernel: a lane owns rows (t, t+1) of state kk.
+// step (12(H+1) rows each; ONE contiguous run of 72(H+1) doubles) from the quotients kCompact left behind.
+//
+// A column is 6(H+1) 16-byte row pairs; thread t owns pairs t, t + 256, ... of EVERY column of the run.
+// Pair (state kk, g) holds rows (2g, 2g+1) of that state: the position (g < 3) or velocity rows of joints
+// (2gp, 2gp+1), non-zero only in columns aa = 2gp (first row) and 2gp+1 (second row), and only for kk > jj
+// (position) or kk == jj+1 (velocity).  So a thread needs at most one 16-byte load per pair for all six columns,
+// and all of them are issued and awaited BEFORE the first store: on gfx950 loads and stores share one counter, and
+// a load whose value is awaited drains every store the wavefront has in flight (round 1's kernel loaded inside
+// its store loop, with ~40 instructions of index arithmetic per store: 5.2 TB/s alone; this one 5.8-6.1).
+// What was measured on the way (tools/h100_overlap.py): the rollouts overlap PERFECTLY with a plain
+// fill of the same buffer (torch's: 9.5 ms || 14.2 ms = 15.1 ms), so the two kinds of work do not compete for
+// anything fundamental; but beside THIS kernel at full occupancy they make no progress at all (the sum of the two
+// times, whatever the stream priorities): every wave slot of the chip bursting 18 KB of stores makes the memory
+// queues so deep that the fill itself slows down (19 ms) and each load and store of the rollouts waits behind them.
+// Hence the dynamic-LDS request (MPC_EXPAND_LDS, unused by the code): it caps the expansion at three workgroups per
+// CU, and at one beside two rollout workgroups.  A persistent grid (a few workgroups walking the runs) would be the
+// direct way to cap it, and was tried in three forms: it never exceeded 3.7 TB/s (tools/fill_bw.hip mode 2 shows the
+// same for a bare fill: multi-wave workgroups striding over private runs in lock step reach 4.0-4.7 TB/s).
+//
+// TMAJOR = false: `src` is the structured layout of the C-ABI ([6H velocity][3H(H+1) position quotients]);
+// TMAJOR = true: the internal workspace layout [iteration t][phase-2 lane] written by prefix_kernel<kCompact>
+// with A.tmajor: perturbation jj is the first (t from 0) or second (t from H - pi + 1) of the lane pair
+// pi = min(jj, H-1-jj); iteration t0 + (kk-1-jj) holds the position quotient of state kk, t0 + (H-jj) the
+// velocity quotient.
 #ifndef MPC_PIPE_CHUNKS
 #define MPC_PIPE_CHUNKS 16         // chunks a large long-horizon batch is pipelined in
 #endif
-#ifndef MPC_EXPAND_THREADS
-#define MPC_EXPAND_THREADS 256   // 6-wave workgroups fill measurably slower than 4- or 8-wave ones (tools/fill_bw.hip)
+constexpr int kExpandThreads = 256;
+#ifndef MPC_EXPAND_LDS
+#define MPC_EXPAND_LDS (48 * 1024) // dynamic LDS per expansion workgroup: unused by the kernel, it caps how many share a CU
 #endif
-constexpr int kExpandThreads = MPC_EXPAND_THREADS;
 
-__global__ __launch_bounds__(kExpandThreads) void expand_kernel(int H, int count, const double *__restrict__ compact,
-                                                                int cstride, double *__restrict__ jac)
+// NP = passes per column = ceil(6(H+1) / 256), a template parameter so that the kernel holds NP loaded pairs and
+// little else (24 VGPRs at NP = 3).
+template <bool TMAJOR, int NP>
+__global__ __launch_bounds__(kExpandThreads) void expand_kernel(int H, int count, const double *__restrict__ src,
+                                                                int cstride, int items, double *__restrict__ jac)
 {
-    // One workgroup per (scenario, step jj): the six columns 6jj..6jj+5 are one contiguous run of 6m
-    // doubles, written front to back, 16 B per lane and 4 KB per workgroup pass (a plain streaming fill).
     typedef double v2d __attribute__((ext_vector_type(2)));
-    const int n = 6 * H, m = 12 * (H + 1), span = 6 * m, H1 = H + 1;
+    const int H1 = H + 1, m = 12 * H1;
     const unsigned bid = mpck::xcd_remap(blockIdx.x, gridDim.x);
     const int s = bid / H, jj = bid - s * H;
     if (s >= count) return;
-    const double *cz = compact + (size_t)s * cstride;
-    double *out = jac + ((size_t)s * n + 6 * jj) * m;
-    const double *pos = cz + 6 * H + 6 * (jj * H - (jj * (jj - 1)) / 2 - jj - 1);
-    const double *vel = cz + 6 * jj;
-    // m is a multiple of 12, so pair p of the run is rows (2g, 2g+1), g = p % 6, of state p / 6 counted
-    // through the six columns; both are advanced incrementally (256 = 42 * 6 + 4)
+    const double *cz = src + (size_t)s * cstride;
     const int tid = (int)threadIdx.x;
-    int g = tid % 6, kk = tid / 6, aa = 0;          // row pair, state within the column, column within the run
-    while (kk >= H1) { kk -= H1; ++aa; }
-    for (int e = 2 * tid; e < span; e += 2 * kExpandThreads) {
+    const int pairs = 6 * H1;                         // 16-byte pairs per column
+    // where state kk's position quotients (six joints, contiguous) and the velocity quotients of step jj start
+    const int pi = (jj < H - 1 - jj) ? jj : H - 1 - jj;
+    const int t0 = (jj == pi) ? 0 : H - pi + 1;
+    const double *pos0 = TMAJOR ? cz + 6 * pi : cz + 6 * H + 6 * (jj * H - (jj * (jj - 1)) / 2 - jj - 1);
+    const int pos_stride = TMAJOR ? items : 6;
+    const int kadd = TMAJOR ? t0 - 1 - jj : 0;        // state kk's entry is pos0[(kk + kadd) * pos_stride + joint]
+    const double *vel = TMAJOR ? cz + 6 * pi + (size_t)(t0 + H - jj) * items : cz + 6 * jj;
+
+    v2d val[NP];
+    int col0[NP];                                     // column of the pair's first row (the second row's is col0 + 1)
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        const int P = tid + kExpandThreads * i;
+        const int kk = P / 6, g = P - 6 * kk;
         const bool is_pos = g < 3;
         const int gp = is_pos ? g : g - 3;
-        const bool hot = (gp == (aa >> 1)) && (is_pos ? (kk > jj) : (kk == jj + 1));
-        v2d v = {0.0, 0.0};
-        if (hot) {
-            const v2d val = *reinterpret_cast<const v2d *>(is_pos ? pos + 6 * kk + 2 * gp : vel + 2 * gp);
-            if (aa & 1) v.y = val.y; else v.x = val.x;
+        const bool live = P < pairs;
+        const bool hot = live && (is_pos ? (kk > jj) : (kk == jj + 1));
+        col0[i] = live ? 2 * gp : -2;
+        val[i] = v2d{0.0, 0.0};
+        if (hot) val[i] = *reinterpret_cast<const v2d *>(is_pos ? pos0 + (size_t)(kk + kadd) * pos_stride + 2 * gp : vel + 2 * gp);
+    }
+    // every load has landed before the first store is issued: no wait for a load can then sit between two stores
+#pragma unroll
+    for (int i = 0; i < NP; ++i) asm volatile("" : "+v"(val[i].x), "+v"(val[i].y));
+    double *out = jac + (size_t)bid * 6 * m + 2 * tid;   // run (s, jj) starts at (s n + 6 jj) m = bid * 6m
+#pragma unroll
+    for (int aa = 0; aa < 6; ++aa) {
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            if (col0[i] >= 0) {
+                const bool mine = col0[i] == (aa & ~1);
+                const v2d v = (aa & 1) ? v2d{0.0, mine ? val[i].y : 0.0} : v2d{mine ? val[i].x : 0.0, 0.0};
+                *reinterpret_cast<v2d *>(out + aa * m + 2 * kExpandThreads * i) = v;
+            }
         }
-        *reinterpret_cast<v2d *>(out + e) = v;
-        g += kExpandThreads % 6;
-        kk += kExpandThreads / 6;
-        if (g >= 6) { g -= 6; ++kk; }
-        while (kk >= H1) { kk -= H1; ++aa; }
+    }
+}
+
+template <bool TMAJOR, int NP>
+hipError_t launch_expand_one(int H, int count, const double *src, int cstride, int items, double *jac, hipStream_t stream)
+{
+    if (MPC_EXPAND_LDS > 48 * 1024) {   // above the default dynamic-LDS limit
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(expand_kernel<TMAJOR, NP>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, MPC_EXPAND_LDS);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL((expand_kernel<TMAJOR, NP>), dim3((unsigned)count * (unsigned)H), dim3(kExpandThreads), MPC_EXPAND_LDS,
+                       stream, H, count, src, cstride, items, jac);
+    return hipGetLastError();
+}
+
+template <bool TMAJOR>
+hipError_t launch_expand_np(int H, int count, const double *src, int cstride, int items, double *jac, hipStream_t stream)
+{
+    switch ((6 * (H + 1) + kExpandThreads - 1) / kExpandThreads) {
+    case 1: return launch_expand_one<TMAJOR, 1>(H, count, src, cstride, items, jac, stream);
+    case 2: return launch_expand_one<TMAJOR, 2>(H, count, src, cstride, items, jac, stream);
+    case 3: return launch_expand_one<TMAJOR, 3>(H, count, src, cstride, items, jac, stream);
+    case 4: return launch_expand_one<TMAJOR, 4>(H, count, src, cstride, items, jac, stream);
+    case 5: return launch_expand_one<TMAJOR, 5>(H, count, src, cstride, items, jac, stream);
+    default: return hipErrorInvalidValue;
     }
 }
 
@@ -657,8 +730,9 @@ bool prefix_supported(const mpc_params &P) { return ur_pattern(P) && (fused_ok(P
 size_t prefix_workspace_doubles_per_scenario(const mpc_params &P)
 {
     if (!ur_pattern(P) || fused_ok(P) || !compact_ok(P)) return 0;
+    // [H+3 iterations][6 ceil(H/2) phase-2 lanes]; equals the structured count 6H + 3H(H+1) for even H
     const size_t H = (size_t)P.horizon;
-    return 6 * H + 3 * H * (H + 1);
+    return (H + 3) * 6 * ((H + 1) / 2);
 }
 
 size_t jacobian_nz_count(int horizon)
@@ -677,7 +751,7 @@ hipError_t launch_prefix_nz(const mpc_params &P, const double *decay, const mpc_
     PrefixArgs A;
     A.decay = decay; A.sc = sc; A.x = x; A.cost = cost; A.grad = grad; A.con = con;
     A.jac = nz;      // kCompact only tests it against NULL ("the quotients are wanted")
-    A.compact = nz; A.cstride = (int)jacobian_nz_count(P.horizon);
+    A.compact = nz; A.cstride = (int)jacobian_nz_count(P.horizon); A.tmajor = 0;
     A.S = g.S; A.items = g.items;
     A.list = nullptr; A.count_dev = nullptr;
     const unsigned grid = (unsigned)((sc.count + g.S - 1) / g.S);
@@ -695,7 +769,7 @@ hipError_t launch_prefix_rows(const mpc_params &P, const double *decay, const mp
     const Geometry g = geometry(P, mode);
     PrefixArgs A;
     A.decay = decay; A.sc = sc; A.x = x; A.cost = cost; A.grad = grad; A.con = con;
-    A.jac = nz; A.compact = nz; A.cstride = (int)jacobian_nz_count(P.horizon);
+    A.jac = nz; A.compact = nz; A.cstride = (int)jacobian_nz_count(P.horizon); A.tmajor = 0;
     A.S = g.S; A.items = g.items;
     A.list = rows.list; A.count_dev = rows.count;
     const unsigned grid = (unsigned)((rows.bound + g.S - 1) / g.S);
@@ -722,10 +796,7 @@ hipError_t launch_sincos_probe(int n, const double *x, double *sn, double *cs, h
 
 hipError_t launch_expand(const mpc_params &P, int count, const double *nz, double *jac, hipStream_t stream)
 {
-    const int H = P.horizon;
-    hipLaunchKernelGGL(expand_kernel, dim3((unsigned)count * (unsigned)H), dim3(kExpandThreads), 0, stream, H, count, nz,
-                       (int)jacobian_nz_count(H), jac);
-    return hipGetLastError();
+    return launch_expand_np<false>(P.horizon, count, nz, (int)jacobian_nz_count(P.horizon), 0, jac, stream);
 }
 
 hipError_t launch_prefix(const mpc_params &P, const double *decay, const mpc_scenarios &sc, const double *x,
@@ -742,7 +813,7 @@ hipError_t launch_prefix(const mpc_params &P, const double *decay, const mpc_sce
     const int H = P.horizon, n = 6 * H, m = 12 * (H + 1);
     PrefixArgs A;
     A.decay = decay; A.sc = sc; A.x = x; A.cost = cost; A.grad = grad; A.con = con; A.jac = jac;
-    A.compact = nullptr; A.cstride = 0;
+    A.compact = nullptr; A.cstride = 0; A.tmajor = 0;
     A.S = g.S; A.items = g.items;
     A.list = nullptr; A.count_dev = nullptr;
     if (mode != kCompact) {
@@ -789,7 +860,7 @@ hipError_t launch_prefix(const mpc_params &P, const double *decay, const mpc_sce
         if (B.grad) B.grad += (size_t)first * n;
         if (B.con) B.con += (size_t)first * m;
         if (B.jac) B.jac += (size_t)first * n * m;
-        B.compact = workspace + (size_t)h * half; B.cstride = (int)per;
+        B.compact = workspace + (size_t)h * half; B.cstride = (int)per; B.tmajor = 1;
         if (piped && i >= 2) err = hipStreamWaitEvent(stream, pipe->drained[h], 0);   // half h is free again
         if (err == hipSuccess) err = launch_mode<kCompact, 512>(P, B, g, (unsigned)cnt, stream);
         if (err != hipSuccess || jac == nullptr) continue;
@@ -800,9 +871,7 @@ hipError_t launch_prefix(const mpc_params &P, const double *decay, const mpc_sce
             if (err != hipSuccess) continue;
             xs = pipe->aux;
         }
-        hipLaunchKernelGGL(expand_kernel, dim3((unsigned)cnt * (unsigned)H), dim3(kExpandThreads), 0, xs, H, cnt,
-                           B.compact, (int)per, B.jac);
-        err = hipGetLastError();
+        err = launch_expand_np<true>(H, cnt, B.compact, (int)per, g.items, B.jac, xs);
         if (err == hipSuccess && piped) err = hipEventRecord(pipe->drained[h], pipe->aux);
         if (err == hipSuccess && used < h + 1) used = h + 1;
     }

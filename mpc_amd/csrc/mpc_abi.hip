@@ -209,8 +209,8 @@ int mpc_set_params(mpc_ctx *ctx, const mpc_params *p, const double *decay_host, 
         ctx->work_doubles = want;
     }
     if (want && !ctx->pipe.aux) {
-        // the expansion (a store-bound fill) runs here beside the next chunk's rollouts: highest priority, so that its
-        // workgroups are dispatched first and the stores never wait for a CU slot behind compute-bound waves
+        // the expansion (a store-bound fill) runs here beside the next chunk's rollouts (the priority of either stream
+        // made no measurable difference: what balances the two kernels is the expansion's occupancy cap, kernels_prefix.hip)
         int prio_low = 0, prio_high = 0;
         MPC_HIP(ctx, hipDeviceGetStreamPriorityRange(&prio_low, &prio_high));
         MPC_HIP(ctx, hipStreamCreateWithPriority(&ctx->pipe.aux, hipStreamNonBlocking, prio_high));

@@ -1,7 +1,5 @@
-import torch, time
-N = 65536*120*252
-a = torch.empty(N, dtype=torch.float64, device="cuda")
-b = torch.empty(N//2, dtype=torch.float64, device="cuda")
+"""Dev tool: what torch's own fill reaches on this box, by buffer size (the ceiling the dc/dx writers are compared with)."""
+import sys, torch
 def t(fn, k=5):
     fn(); torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -9,7 +7,9 @@ def t(fn, k=5):
     for _ in range(k): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1)/k
-ms = t(lambda: a.zero_()); print(f"zero_  {a.numel()*8/ms/1e6:.1f} GB/s write  ({ms:.3f} ms)")
-ms = t(lambda: a.fill_(1.5)); print(f"fill_  {a.numel()*8/ms/1e6:.1f} GB/s write  ({ms:.3f} ms)")
-ms = t(lambda: a[:N//2].copy_(b)); print(f"copy_  {b.numel()*8*2/ms/1e6:.1f} GB/s read+write ({ms:.3f} ms)")
-ms = t(lambda: torch.cuda.memset if False else a.view(torch.uint8).zero_()); print(f"zero_u8 {a.numel()*8/ms/1e6:.1f} GB/s")
+for gb in (4, 16, 48, 96):
+    N = int(gb * 1e9 / 8)
+    a = torch.empty(N, dtype=torch.float64, device="cuda")
+    ms = t(lambda: a.zero_()); print(f"{gb:3d} GB zero_  {N*8/ms/1e6:7.1f} GB/s ({ms:.3f} ms)")
+    ms = t(lambda: a.fill_(1.5)); print(f"{gb:3d} GB fill_  {N*8/ms/1e6:7.1f} GB/s ({ms:.3f} ms)", flush=True)
+    del a

@@ -1,4 +1,5 @@
 // Dev microbenchmark: how fast can waves stream per-wave-private 241,920-byte blocks to HBM?
+// vy = 1: half of the doubles non-zero; vy = 0: all zeros (does the rate depend on the data?)
 // All accesses are in bounds by construction: block b covers [b*BLK, (b+1)*BLK) doubles of a
 // buffer of nblocks*BLK doubles.
 #include <hip/hip_runtime.h>
@@ -12,12 +13,12 @@ constexpr int BLK = 120 * 252;  // doubles per block
 // mode 0: flat aligned 1 KB stores; mode 1: 252-double columns as 64+62 lane stores;
 // mode 2: flat, but consecutive blocks of the grid interleave chunks (grid-stride over the whole buffer)
 template <int MODE>
-__global__ __launch_bounds__(256) void k(double *out, int nblocks, int lds_pad)
+__global__ __launch_bounds__(256) void k(double *out, int nblocks, int lds_pad, double vy)
 {
     extern __shared__ double pad[];
     const int lane = threadIdx.x;
     if (lds_pad < 0) pad[lane] = 1.0;  // keep the LDS allocation alive
-    const v2d z = {0.0, (double)lane};
+    const v2d z = {0.0, vy * (double)lane};
     if (MODE == 0) {
         double *base = out + (size_t)blockIdx.x * BLK;
         for (int c = 0; c < BLK / 128; ++c) *reinterpret_cast<v2d *>(base + 128 * c + 2 * lane) = z;
@@ -34,7 +35,7 @@ __global__ __launch_bounds__(256) void k(double *out, int nblocks, int lds_pad)
         // 256-thread workgroup streams 4 consecutive blocks; all 4 waves work on the same block:
         // MODE 3: wave w takes columns [30w, 30w+30); MODE 4: wave w takes columns c = w (mod 4)
         const int wave = threadIdx.x >> 6, ln = threadIdx.x & 63;
-        const v2d zz = {0.0, (double)ln};
+        const v2d zz = {0.0, vy * (double)ln};
         for (int b = 0; b < 4; ++b) {
             double *base = out + ((size_t)blockIdx.x * 4 + b) * BLK;   // blockIdx.x < nblocks/4
             for (int i = 0; i < 30; ++i) {
@@ -51,7 +52,7 @@ __global__ __launch_bounds__(256) void k(double *out, int nblocks, int lds_pad)
         const size_t total = (size_t)nblocks * BLK / 2;                 // v2d elements
         v2d *o = reinterpret_cast<v2d *>(out);
         const size_t base = (size_t)blockIdx.x * 256 * U;
-        const v2d zz = {0.0, 1.0};
+        const v2d zz = {0.0, vy};
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const size_t i = base + (size_t)u * 256 + threadIdx.x;
@@ -80,25 +81,26 @@ int main(int argc, char **argv)
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
     const size_t bytes = sizeof(double) * (size_t)nblocks * BLK;
+    for (double vy : {1.0, 0.0})
     for (int lds : {0, 20 * 1024}) {
         for (int mode = 0; mode < 8; ++mode) {
             float best = 1e9;
             for (int rep = 0; rep < 4; ++rep) {
                 hipEventRecord(e0);
-                if (mode == 0) hipLaunchKernelGGL(k<0>, dim3(nblocks), dim3(64), lds, 0, buf, nblocks, 0);
-                if (mode == 1) hipLaunchKernelGGL(k<1>, dim3(nblocks), dim3(64), lds, 0, buf, nblocks, 0);
-                if (mode == 2) hipLaunchKernelGGL(k<2>, dim3(256 * 8), dim3(64), lds, 0, buf, nblocks, 0);
-                if (mode == 3) hipLaunchKernelGGL(k<3>, dim3(nblocks / 4), dim3(256), 3 * lds, 0, buf, nblocks, 0);
-                if (mode == 4) hipLaunchKernelGGL(k<4>, dim3(nblocks / 4), dim3(256), 3 * lds, 0, buf, nblocks, 0);
-                if (mode == 6) hipLaunchKernelGGL(k<6>, dim3((unsigned)(((size_t)nblocks * BLK / 2 + 1023) / 1024)), dim3(256), 0, 0, buf, nblocks, 0);
-                if (mode == 7) hipLaunchKernelGGL(k<7>, dim3((unsigned)(((size_t)nblocks * BLK / 2 + 4095) / 4096)), dim3(256), 0, 0, buf, nblocks, 0);
-                if (mode == 5) hipLaunchKernelGGL(k<5>, dim3(nblocks), dim3(64), lds, 0, buf, nblocks, 0);
+                if (mode == 0) hipLaunchKernelGGL(k<0>, dim3(nblocks), dim3(64), lds, 0, buf, nblocks, 0, vy);
+                if (mode == 1) hipLaunchKernelGGL(k<1>, dim3(nblocks), dim3(64), lds, 0, buf, nblocks, 0, vy);
+                if (mode == 2) hipLaunchKernelGGL(k<2>, dim3(256 * 8), dim3(64), lds, 0, buf, nblocks, 0, vy);
+                if (mode == 3) hipLaunchKernelGGL(k<3>, dim3(nblocks / 4), dim3(256), 3 * lds, 0, buf, nblocks, 0, vy);
+                if (mode == 4) hipLaunchKernelGGL(k<4>, dim3(nblocks / 4), dim3(256), 3 * lds, 0, buf, nblocks, 0, vy);
+                if (mode == 6) hipLaunchKernelGGL(k<6>, dim3((unsigned)(((size_t)nblocks * BLK / 2 + 1023) / 1024)), dim3(256), 0, 0, buf, nblocks, 0, vy);
+                if (mode == 7) hipLaunchKernelGGL(k<7>, dim3((unsigned)(((size_t)nblocks * BLK / 2 + 4095) / 4096)), dim3(256), 0, 0, buf, nblocks, 0, vy);
+                if (mode == 5) hipLaunchKernelGGL(k<5>, dim3(nblocks), dim3(64), lds, 0, buf, nblocks, 0, vy);
                 hipEventRecord(e1);
                 hipEventSynchronize(e1);
                 float ms; hipEventElapsedTime(&ms, e0, e1);
                 if (ms < best) best = ms;
             }
-            printf("lds=%5d mode=%d: %.3f ms  %.0f GB/s\n", lds, mode, best, bytes / best / 1e6);
+            printf("vy=%.0f lds=%5d mode=%d: %.3f ms  %.0f GB/s\n", vy, lds, mode, best, bytes / best / 1e6);
         }
     }
     if (hipGetLastError() != hipSuccess) printf("HIP error\n");
