@@ -338,6 +338,32 @@ def test_h100_two_stream_pipeline_equals_plain_chunks():
     np.testing.assert_allclose(full.con_jac[torch.as_tensor(idx, device=ctx.device)].cpu().numpy(), jac_o, rtol=1e-9, atol=1e-10)
 
 
+def test_odd_long_horizon_through_the_two_stream_pipeline():
+    """An ODD long horizon (H = 43: the middle perturbation has no partner, and the workspace's
+    iteration-major layout has unused slots) at a batch size that takes the two-stream pipeline: same bits as
+    calls small enough for the one-stream route, which the oracle checks."""
+    mp = params_for(43)
+    N = 2304
+    ctx = _ctx(mp, N)
+    co, hs = host_scenarios(mp, N, motion="angular", cfg_id=12, near_bounds=True)
+    sc, x = to_device(ctx, hs)
+    full = ctx.eval_fd(sc, x)
+    torch.cuda.synchronize()
+    for a in range(0, N, 768):
+        p = ctx.eval_fd(sc.slice(a, a + 768), x[a:a + 768])
+        torch.cuda.synchronize()
+        assert torch.equal(p.con_jac, full.con_jac[a:a + 768]) and torch.equal(p.grad, full.grad[a:a + 768])
+        assert torch.equal(p.cost, full.cost[a:a + 768]) and torch.equal(p.con, full.con[a:a + 768])
+    idx = np.array([0, 1151, 1152, 2303])
+    sub = {k: (None if v is None else v[idx]) for k, v in hs.as_oracle_dict().items()}
+    c_o, g_o, con_o, jac_o = co.eval_fd(sub)
+    assert_cost_close(full.cost.cpu().numpy()[idx], c_o)
+    assert_grad_close(full.grad.cpu().numpy()[idx], g_o)
+    np.testing.assert_allclose(full.con_jac[torch.as_tensor(idx, device=ctx.device)].cpu().numpy(), jac_o, rtol=1e-9, atol=1e-10)
+    z = ctx.eval_fd_nz(sc, x)
+    assert torch.equal(ctx.expand_jacobian(z.con_jac_nz), full.con_jac)
+
+
 @pytest.mark.parametrize("H,N", [(1, 37), (3, 29), (20, 512), (100, 24)])
 def test_structured_jacobian_equals_dense(H, N):
     """mpc_eval_fd_nz: same f, grad f, c as mpc_eval_fd, and its structured dc/dx expands (on the device with
