@@ -294,6 +294,16 @@ def single_tick_latency(device, with_cpu):
         one.compute_control(*dicts20(i))
         t20.append(time.perf_counter() - t0)
     out["H20_ms_per_tick"] = 1e3 * float(np.median(t20))
+    # the same ticks with minimize replaced by the device-resident solver (GpuURMPC(solver="resident"): same controls)
+    for key, mp_k, dk, rows_k in (("resident_solver_ms_per_tick", mp1, dicts, rows), ("H20_resident_solver_ms_per_tick", mp20, dicts20, rows20)):
+        GpuURMPC(mp_k, device=device, solver="resident").compute_control(*dk(rows_k[0]))
+        tr = []
+        for i in rows_k:
+            one = GpuURMPC(mp_k, device=device, solver="resident")
+            t0 = time.perf_counter()
+            one.compute_control(*dk(i))
+            tr.append(time.perf_counter() - t0)
+        out[key] = 1e3 * float(np.median(tr))
     out["H20_note"] = ("same drop-in class at H=20 (scipy's compiled SLSQP core on one host core, every callback served by "
                        "the device); the numpy path's H=20 tick is cpu_baseline.solves_value (about 4 s)")
     return out

@@ -23,6 +23,22 @@ def _dicts(g, i):
     return js, ee, tg, bs
 
 
+def test_drop_in_class_with_the_resident_solver_equals_scipy_minimize():
+    """solver="resident" replaces nothing but scipy's minimize: same previous_solution and control as the default
+    class, bit for bit, over warm-started ticks (H = 3 and 20), and the same early exit."""
+    for H in (3, 20):
+        g = np.load(os.path.join(os.path.dirname(__file__), "golden", f"solve_H{H}.npz"), allow_pickle=False)
+        a = GpuURMPC(MpcParams.reference_yaml_defaults(horizon=H))
+        b = GpuURMPC(MpcParams.reference_yaml_defaults(horizon=H), solver="resident")
+        js, ee, tg, bs = _dicts(g, 0)
+        for tick in range(3):
+            ua, ub = a.compute_control(js, ee, tg, bs), b.compute_control(js, ee, tg, bs)
+            assert np.array_equal(ua, ub) and np.array_equal(a.previous_solution, b.previous_solution)
+            assert b.last_result.success and b.last_result.nit == a.last_result.nit
+    with pytest.raises(ValueError):
+        GpuURMPC(solver="newton")
+
+
 @pytest.mark.parametrize("H", [1, 3, 20])
 def test_compute_control_matches_reference(golden_dir, H):
     path = os.path.join(golden_dir, f"solve_H{H}.npz")

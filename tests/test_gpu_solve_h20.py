@@ -64,12 +64,16 @@ def test_h20_solves_match_reference(golden_dir, kind):
             solver.close()
 
 
-def test_h20_drop_in_class_matches_reference(golden_dir):
+@pytest.mark.parametrize("solver", ["scipy", "resident"])
+def test_h20_drop_in_class_matches_reference(golden_dir, solver):
+    """GpuURMPC.compute_control against the reference's own two-tick solves (ur_mpc.py:83-247), with scipy's
+    minimize around the device callbacks and with minimize replaced by the device-resident solver."""
     from mpc_amd.ur_mpc import GpuURMPC
 
     g = _golden(golden_dir, "solve_H20_cfg3.npz")
-    for i in (0, g["q0"].shape[0] - 1):                     # one angular, one linear (scipy drives these: slow)
-        mpc = GpuURMPC(MpcParams.reference_yaml_defaults(horizon=20))
+    rows = (0, g["q0"].shape[0] - 1) if solver == "scipy" else range(g["q0"].shape[0])   # scipy drives these: slow
+    for i in rows:
+        mpc = GpuURMPC(MpcParams.reference_yaml_defaults(horizon=20), solver=solver)
         b = g["base"][i]
         args = ({"position": g["q0"][i].copy(), "velocity": np.zeros(6)},
                 {"position": g["ee"][i, :3].copy(), "orientation": g["ee"][i, 3:].copy()},
