@@ -79,6 +79,9 @@ int fail(mpc_ctx *ctx, int code, const char *fmt, ...)
 
 int hip_fail(mpc_ctx *ctx, hipError_t e, const char *what)
 {
+    // the error is reported through the return code and mpc_last_error; the runtime's own "last error" is cleared,
+    // or the caller's next launch check (torch's, say) would trip over an error that was already handled here
+    (void)hipGetLastError();
     return fail(ctx, MPC_ERR_HIP, "%s: %s", what, hipGetErrorString(e));
 }
 

@@ -625,6 +625,65 @@ def test_qp_step_rejects_an_index_outside_the_state_rows():
     assert float(L[1].abs().sum()) > 0 and float(s_out[0].abs().sum()) > 0 and float(s_out[1].abs().sum()) == 0
 
 
+def test_qp_workspace_allocation_failure_is_reported_and_recoverable():
+    """mpc_qp_step allocates its teams' workspace on first use (~0.5 GB at H = 20 for a large context).  With the
+    device's memory taken, the call fails with the HIP error in the context's message, launches nothing (state rows
+    untouched) and leaves the context usable: the same call succeeds once memory is free again."""
+    from helpers import host_scenarios
+    from mpc_amd import _ffi
+    from mpc_amd.batch import MpcContext
+    from mpc_amd.scenarios import to_device
+
+    mp = MpcParams.reference_yaml_defaults(horizon=20)
+    rows = 4
+    warm = MpcContext(mp, 8, 0)                                        # code objects loaded, small workspace
+    ctx = MpcContext(mp, 65536, 0)                                     # 512 teams: ~0.5 GB on first use
+    _, hs = host_scenarios(mp, rows, motion="linear", cfg_id=24)
+    n, m = mp.n, mp.m
+    dev = ctx.device
+    z = lambda *shape: torch.zeros(shape, dtype=torch.float64, device=dev)
+
+    def step(c):
+        sc, x = to_device(c, hs)
+        r = c.eval_fd_nz(sc, x)
+        L, R, V = z(rows, (n + 1) * n // 2 + 1), z(rows, m + 2 * n), z(rows, n)
+        lim = torch.as_tensor(np.tile(mp.v_lim, mp.horizon)).to(dev)
+        index = torch.arange(rows, dtype=torch.int32, device=dev)
+        flags = torch.ones(rows, dtype=torch.int32, device=dev)
+        lo, hi = (-lim - x).contiguous(), (lim - x).contiguous()
+        s_out, r_out = z(rows, n), z(rows, m)
+        mode = torch.zeros(rows, dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()
+        return L, mode, s_out, lambda: c._lib.mpc_qp_step(
+            c._ctx, rows, rows, index.data_ptr(), flags.data_ptr(), lo.data_ptr(), hi.data_ptr(), z(rows, n).data_ptr(),
+            L.data_ptr(), r.grad.data_ptr(), r.con.data_ptr(), r.con_jac_nz.data_ptr(), R.data_ptr(), V.data_ptr(),
+            s_out.data_ptr(), r_out.data_ptr(), mode.data_ptr(), c._stream()), (r, R, V, lo, hi, index, flags, r_out)
+
+    Lw, mode_w, s_w, call_w, keep_w = step(warm)
+    assert call_w() == 0
+    torch.cuda.synchronize()
+    assert mode_w.cpu().tolist() == [1] * rows
+    L, mode, s_out, call, keep = step(ctx)
+    hog = []                                                           # take the device's memory down to < 64 MB free
+    for chunk in (8 << 30, 1 << 30, 64 << 20):
+        try:
+            while len(hog) < 4096:
+                hog.append(torch.empty(chunk, dtype=torch.uint8, device=dev))
+        except (torch.cuda.OutOfMemoryError, RuntimeError):
+            pass
+    rc = call()
+    assert rc != 0
+    with pytest.raises(_ffi.MpcError, match="memory|hipMalloc|alloc"):
+        _ffi.check(ctx._ctx, rc)
+    torch.cuda.synchronize()
+    del hog
+    torch.cuda.empty_cache()
+    assert float(L.abs().sum()) == 0 and mode.cpu().tolist() == [0] * rows    # nothing ran
+    assert call() == 0
+    torch.cuda.synchronize()
+    assert mode.cpu().tolist() == [1] * rows and torch.equal(s_out, s_w) and torch.equal(L, Lw)
+
+
 def test_prepare_tick_rejects_an_in_place_warm_start_shift():
     """x0[i] = prev_solution[i + 6]: the same buffer for both would be read after it was overwritten."""
     import ctypes as C
