@@ -425,7 +425,7 @@ def test_different_cost_and_constraint_time_steps(algo, H):
         assert torch.equal(ctx.expand_jacobian(z.con_jac_nz), res.con_jac) and torch.equal(z.grad, res.grad)
 
 
-@pytest.mark.parametrize("H", [40, 41, 42, 43, 170, 171, 255])
+@pytest.mark.parametrize("H", [40, 41, 42, 43, 64, 150, 170, 171, 255])
 def test_horizon_boundaries_of_the_kernel_variants(H):
     """MPC_ALGO_AUTO across the hand-overs: fused kernel (LDS image, H <= ~40), long-horizon two-kernel route
     (up to H = 170), plain rollout kernel beyond (up to MPC_MAX_HORIZON = 255)."""
