@@ -531,7 +531,10 @@ SPMD_HD int nnls(const Team &T, const Work &W, int mrow, int ncol, int mg, doubl
 #define MPC_QP_NB 2
 #endif
 #ifndef MPC_QP_ROWS
-#define MPC_QP_ROWS 2
+#define MPC_QP_ROWS 1              // rows per lane; see lsq's row loop for why one beats two on the device
+#endif
+#ifndef MPC_QP_SNAKE
+#define MPC_QP_SNAKE 1
 #endif
 
 struct RowDesc {
@@ -660,7 +663,9 @@ __device__ __forceinline__ void transform_cols_wave(const Work &W, int n, int mg
         const int c2 = u - (c * (c + 1)) / 2;
         tri[j] = W.E[EO(jb + c2) + (c - c2)];
     }
-    const double fv = W.ff[jb + (lane16 < NC ? lane16 : 0)];
+    double fv[(NC + 15) / 16];                             // f(jb + t) in lane t % 16 of register t / 16
+    SPMD_UNROLL
+    for (int j = 0; j < (NC + 15) / 16; ++j) fv[j] = W.ff[jb + (16 * j + lane16 < NC ? 16 * j + lane16 : 0)];
     double val[R][NB];
     SPMD_UNROLL
     for (int r = 0; r < R; ++r) {
@@ -691,7 +696,7 @@ __device__ __forceinline__ void transform_cols_wave(const Work &W, int n, int mg
             }
         });
         constexpr int ud = (c * (c + 1)) / 2 + c;
-        const double diag = row_bcast<ud % 16>(tri[ud / 16]), fj = row_bcast<c>(fv);
+        const double diag = row_bcast<ud % 16>(tri[ud / 16]), fj = row_bcast<c % 16>(fv[c / 16]);
         SPMD_UNROLL
         for (int r = 0; r < R; ++r) {
             const double orig = (c % 6 == d[r].a) ? val[r][c / 6] : 0.0;
@@ -885,7 +890,7 @@ __device__ __attribute__((noinline)) void transform_rows_call(const double *E, c
                                                               double *AT, int H, const double *cvals, const double *nz,
                                                               const double *lo, const double *hi, int row0, int row1, int store)
 {
-    static_assert(R == 2, "two rows per lane");
+    static_assert(R == 1 || R == 2, "one or two rows per lane (row1 is ignored for one)");
     Work W{};
     if constexpr (LDS) {
         typedef __attribute__((address_space(3))) double LdsDouble;
@@ -903,7 +908,13 @@ __device__ __attribute__((noinline)) void transform_rows_call(const double *E, c
     W.AT = AT;
     const int rows[2] = {row0, row1};
     double *const dst[2] = {AT + row0, AT + row1};
-    transform_rows<2, true>(W, scalar_again(H), rows, cvals, nz, lo, hi, dst, store != 0, AT);
+    if constexpr (R == 2) {
+        transform_rows<2, true>(W, scalar_again(H), rows, cvals, nz, lo, hi, dst, store != 0, AT);
+    } else {
+        const int rows1[1] = {row0};
+        double *const dst1[1] = {AT + row0};
+        transform_rows<1, true>(W, scalar_again(H), rows1, cvals, nz, lo, hi, dst1, store != 0, AT);
+    }
 }
 #endif
 
@@ -1016,10 +1027,24 @@ SPMD_HD int lsq(const Team &T, const Work &W, int H, const double *g, const doub
     //      dealt out in the order of work_order: a row's work begins at its first nonzero block, and a wavefront walks
     //      from the earliest block any of its rows needs, so rows that begin late share wavefronts
     //      (m + 2n = 12 (2H + 1) is a multiple of 2, 3 and 4).
+    //      One row per lane and two passes (round 2, late): with two rows per lane the first two wavefronts held every
+    //      row that begins at block 0 and walked all of e while the other two had 42 % and 9 % of that to do; with one
+    //      row per lane the heavy rows spread over three wavefronts' first pass at 3 instead of 5 instructions per
+    //      entry of e, and the second pass is dealt out in the opposite direction, so a wavefront's two walks add up
+    //      to 412 .. 481 block-squares instead of 400 .. 9 at the two-row rate: -7 % on whole solves.
     {
         const int per = mg / MPC_QP_ROWS, width = T.size() < 64 ? T.size() : 64;
         const int waves = T.size() / width;
+#if MPC_QP_SNAKE
+        // passes take turns in direction: the wavefront that got the rows with the most work in one pass gets those
+        // with the least in the next
+        for (int pass = 0, base = 0; pass * T.size() < per; ++pass) {
+            const int wv = (T.tid() / width + T.turn()) % waves;
+            base = pass * T.size() + ((pass & 1) ? waves - 1 - wv : wv) * width;
+            if (base >= per) continue;
+#else
         for (int base = ((T.tid() / width + T.turn()) % waves) * width; base < per; base += T.size()) {
+#endif
             const int want = base + T.tid() % width;
             const bool mine = want < per;
             const int i = mine ? want : per - 1;
@@ -1039,7 +1064,8 @@ SPMD_HD int lsq(const Team &T, const Work &W, int H, const double *g, const doub
                     e_lds = (unsigned)(unsigned long long)(LdsDouble *)W.E;
                     ff_lds = (unsigned)(unsigned long long)(LdsDouble *)W.ff;
                 }
-                transform_rows_call<2, Team::kLdsPool>(W.E, W.ff, e_lds, ff_lds, W.AT, H, cvals, nz, lo, hi, rows[0], rows[1], mine ? 1 : 0);
+                transform_rows_call<MPC_QP_ROWS, Team::kLdsPool>(W.E, W.ff, e_lds, ff_lds, W.AT, H, cvals, nz, lo, hi, rows[0],
+                                                                 rows[MPC_QP_ROWS - 1], mine ? 1 : 0);
             } else
 #endif
                 transform_rows<MPC_QP_ROWS, true>(W, H, rows, cvals, nz, lo, hi, dst, mine, W.AT);
