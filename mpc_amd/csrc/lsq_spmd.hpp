@@ -540,13 +540,23 @@ SPMD_HD int nnls(const Team &T, const Work &W, int mrow, int ncol, int mg, doubl
 struct RowDesc {
     int a, first, last, kind, kk;      // sub-blocks [first, last] hold the row's nonzeros, in column 6 * jj + a of each
     double hval;
+    double hval_twin;                  // kind 3 (lower bound of variable v): h of the upper-bound row of v, -hi[v]
 };
+
+// The upper-bound row of a variable is the lower-bound row's negative, entry for entry: the row is -e_v instead of
+// +e_v, every product of the triangular solve changes its sign exactly, sums of terms that all changed sign round to
+// the negative of the sum, and a sum or difference that is zero is +0.0 in both rows (it starts from +0.0, and
+// x - x = +0.0).  So the "twin" is written as 0.0 - (the lower-bound row's entry) -- -x for a nonzero x, +0.0 for
+// +0.0 -- and never computed: a third of the rows that begin late, a sixth of the transform's work.  The twins' h
+// entries are written with their rows' (they need the row's sum against f, which is not stored); the other n columns
+// by one pass of the whole team after the transform (contiguous loads and stores, 960 bytes per column).
+SPMD_HD inline double twin_of(double v) { return 0.0 - v; }
 
 SPMD_HD inline RowDesc describe_row(int H, int i, const double *cvals, const double *lo, const double *hi)
 {
     const int n = 6 * H, m = 12 * (H + 1);
     RowDesc d;
-    d.a = 0; d.first = H; d.last = -1; d.kind = 0; d.kk = 0;
+    d.a = 0; d.first = H; d.last = -1; d.kind = 0; d.kk = 0; d.hval_twin = 0.0;
     if (i < m) {
         const int st = i / 12, r = i % 12;
         d.hval = -cvals[i];
@@ -554,7 +564,7 @@ SPMD_HD inline RowDesc describe_row(int H, int i, const double *cvals, const dou
         else { d.a = r - 6; if (st >= 1) { d.first = st - 1; d.last = st - 1; d.kind = 2; } }                // velocity row
     } else if (i < m + n) {
         const int v = i - m;
-        d.a = v % 6; d.first = v / 6; d.last = d.first; d.kind = 3; d.hval = lo[v];
+        d.a = v % 6; d.first = v / 6; d.last = d.first; d.kind = 3; d.hval = lo[v]; d.hval_twin = -hi[v];
     } else {
         const int v = i - m - n;
         d.a = v % 6; d.first = v / 6; d.last = d.first; d.kind = 4; d.hval = -hi[v];
@@ -789,27 +799,28 @@ SPMD_HD inline void transform_cols(const Work &W, int n, int mg, int H, const do
 #undef EO
 }
 
-// Row number p of [g h] in order of the work its transform takes: the 6H position rows of states 1 .. H (nonzeros from
-// block 0 on), then for f = 0 .. H - 1 the rows that begin at block f (the velocity rows of state f + 1, the lower and
-// the upper bound rows of its six variables), last the 12 rows of state 0 (no variable enters them).
+// Row number p of the m + n rows of [g h] that are computed (the upper-bound rows are written as their lower-bound
+// rows' twins) in order of the work its transform takes: the 6H position rows of states 1 .. H (nonzeros from block 0
+// on), then for f = 0 .. H - 1 the rows that begin at block f (the velocity rows of state f + 1, the lower-bound rows
+// of its six variables), last the 12 rows of state 0 (no variable enters them).
 SPMD_HD inline int work_order(int H, int p)
 {
     const int n = 6 * H, m = 12 * (H + 1);
     if (p < n) return 12 * (p / 6 + 1) + p % 6;
     const int q = p - n;
-    if (q < 18 * H) {
-        const int f = q / 18, r = q % 18;
+    if (q < 12 * H) {
+        const int f = q / 12, r = q % 12;
         if (r < 6) return 12 * (f + 1) + 6 + r;
-        if (r < 12) return m + 6 * f + (r - 6);
-        return m + n + 6 * f + (r - 12);
+        return m + 6 * f + (r - 6);
     }
-    return q - 18 * H;
+    return q - 12 * H;
 }
 
 template <int R, bool COOP = false>
 SPMD_HD inline void transform_rows(const Work &W, int H, const int *rows, const double *cvals, const double *nz,
                                    const double *lo, const double *hi, double *const *dst, bool store = true,
-                                   double *base = nullptr)      // COOP: dst[r] = base + rows[r], base the same in every lane
+                                   double *base = nullptr,      // COOP: dst[r] = base + rows[r], base the same in every lane
+                                   bool twin = false)           // also write the twin's h (row + n, column n) of every lower-bound row
 {
     const int n = 6 * H, mg = 12 * (H + 1) + 2 * n;
     RowDesc d[R];
@@ -860,7 +871,10 @@ SPMD_HD inline void transform_rows(const Work &W, int H, const int *rows, const 
     }
     if (store) {
         SPMD_UNROLL
-        for (int r = 0; r < R; ++r) dst[r][(size_t)n * mg] = d[r].hval - th[r];
+        for (int r = 0; r < R; ++r) {
+            dst[r][(size_t)n * mg] = d[r].hval - th[r];
+            if (twin && d[r].kind == 3) dst[r][(size_t)n * mg + n] = d[r].hval_twin - twin_of(th[r]);
+        }
     }
 }
 
@@ -909,11 +923,11 @@ __device__ __attribute__((noinline)) void transform_rows_call(const double *E, c
     const int rows[2] = {row0, row1};
     double *const dst[2] = {AT + row0, AT + row1};
     if constexpr (R == 2) {
-        transform_rows<2, true>(W, scalar_again(H), rows, cvals, nz, lo, hi, dst, store != 0, AT);
+        transform_rows<2, true>(W, scalar_again(H), rows, cvals, nz, lo, hi, dst, store != 0, AT, true);
     } else {
         const int rows1[1] = {row0};
         double *const dst1[1] = {AT + row0};
-        transform_rows<1, true>(W, scalar_again(H), rows1, cvals, nz, lo, hi, dst1, store != 0, AT);
+        transform_rows<1, true>(W, scalar_again(H), rows1, cvals, nz, lo, hi, dst1, store != 0, AT, true);
     }
 }
 #endif
@@ -1026,14 +1040,14 @@ SPMD_HD int lsq(const Team &T, const Work &W, int H, const double *g, const doub
     //      storing), so that on the device a wavefront loads the entries of e once for all its lanes; and the rows are
     //      dealt out in the order of work_order: a row's work begins at its first nonzero block, and a wavefront walks
     //      from the earliest block any of its rows needs, so rows that begin late share wavefronts
-    //      (m + 2n = 12 (2H + 1) is a multiple of 2, 3 and 4).
+    //      (m + n = 18 H + 12 computed rows, a multiple of 2, 3 and 6; the n upper-bound rows are written as twins).
     //      One row per lane and two passes (round 2, late): with two rows per lane the first two wavefronts held every
     //      row that begins at block 0 and walked all of e while the other two had 42 % and 9 % of that to do; with one
     //      row per lane the heavy rows spread over three wavefronts' first pass at 3 instead of 5 instructions per
     //      entry of e, and the second pass is dealt out in the opposite direction, so a wavefront's two walks add up
     //      to 412 .. 481 block-squares instead of 400 .. 9 at the two-row rate: -7 % on whole solves.
     {
-        const int per = mg / MPC_QP_ROWS, width = T.size() < 64 ? T.size() : 64;
+        const int per = (mg - n) / MPC_QP_ROWS, width = T.size() < 64 ? T.size() : 64;   // 18H + 12 computed rows
         const int waves = T.size() / width;
 #if MPC_QP_SNAKE
         // passes take turns in direction: the wavefront that got the rows with the most work in one pass gets those
@@ -1068,7 +1082,22 @@ SPMD_HD int lsq(const Team &T, const Work &W, int H, const double *g, const doub
                                                                  rows[MPC_QP_ROWS - 1], mine ? 1 : 0);
             } else
 #endif
-                transform_rows<MPC_QP_ROWS, true>(W, H, rows, cvals, nz, lo, hi, dst, mine, W.AT);
+                transform_rows<MPC_QP_ROWS, true>(W, H, rows, cvals, nz, lo, hi, dst, mine, W.AT, true);
+        }
+    }
+    T.sync();
+    // the upper-bound rows: twins of the lower-bound rows (eight loads in flight per thread: the matrix is in global memory)
+    for (int e0 = T.tid(); e0 < n * n; e0 += 8 * T.size()) {
+        double v[8];
+        SPMD_UNROLL
+        for (int q = 0; q < 8; ++q) {
+            const int e = e0 + q * T.size(), j = e / n;
+            v[q] = e < n * n ? W.AT[(size_t)j * mg + m + (e - j * n)] : 0.0;
+        }
+        SPMD_UNROLL
+        for (int q = 0; q < 8; ++q) {
+            const int e = e0 + q * T.size(), j = e / n;
+            if (e < n * n) W.AT[(size_t)j * mg + m + n + (e - j * n)] = twin_of(v[q]);
         }
     }
     QP_MARK(T, 3);   // transform
