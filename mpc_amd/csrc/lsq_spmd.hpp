@@ -1050,12 +1050,18 @@ SPMD_HD int lsq(const Team &T, const Work &W, int H, const double *g, const doub
         const int per = (mg - n) / MPC_QP_ROWS, width = T.size() < 64 ? T.size() : 64;   // 18H + 12 computed rows
         const int waves = T.size() / width;
 #if MPC_QP_SNAKE
-        // passes take turns in direction: the wavefront that got the rows with the most work in one pass gets those
-        // with the least in the next
-        for (int pass = 0, base = 0; pass * T.size() < per; ++pass) {
-            const int wv = (T.tid() / width + T.turn()) % waves;
-            base = pass * T.size() + ((pass & 1) ? waves - 1 - wv : wv) * width;
-            if (base >= per) continue;
+        // Groups of `width` rows, in the order of work_order (most work first), each to the wavefront with the least
+        // work so far (a group costs the square of the blocks its FIRST row still has to walk; every wavefront runs
+        // the same little computation and keeps its own groups, in order).
+        const int wv = (T.tid() / width + T.turn()) % waves;
+        int load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int base = 0; base < per; base += width) {
+            const int p0 = base * MPC_QP_ROWS;                     // the group's first row, in work order
+            const int f0 = p0 < n ? 0 : (p0 - n < 12 * H ? (p0 - n) / 12 : H);
+            int owner = 0;
+            for (int v = 1; v < waves && v < 8; ++v) owner = load[v] < load[owner] ? v : owner;
+            load[owner] += (H - f0) * (H - f0) + 1;
+            if (owner != wv) continue;
 #else
         for (int base = ((T.tid() / width + T.turn()) % waves) * width; base < per; base += T.size()) {
 #endif
