@@ -30,7 +30,7 @@ if ROOT not in sys.path:
 from mpc_amd import _ffi  # noqa: E402
 from mpc_amd.batch import EvalResult, MpcContext  # noqa: E402
 from mpc_amd.params import MpcParams  # noqa: E402
-from mpc_amd.scenarios import DeviceKinematics, make_scenarios, to_device  # noqa: E402
+from mpc_amd.scenarios import SWEEP_ROWS, DeviceKinematics, make_scenarios, make_sweep, to_device  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 FP64_VALU_PEAK_TF = 78.6     # 256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz
@@ -225,9 +225,59 @@ def executed_fp64(H, S, variant, kernel_ms):
         if t.get("horizon") == H and t.get("variant") in wanted and "expand" not in t.get("kernel", ""):
             flops = float(t["executed_flops_per_launch"]) / float(t["scenarios"]) * S
             tf = flops / (kernel_ms * 1e-3) / 1e12
-            return {"executed_tflops": tf, "executed_frac_of_fp64_valu_peak": tf / FP64_VALU_PEAK_TF,
-                    "executed_flops_per_eval": flops / S, "lane_occupancy": t.get("lane_occupancy"), "source": src}
+            occ = t.get("lane_occupancy")
+            out = {"executed_tflops_all_64_lanes": tf, "executed_frac_of_fp64_valu_peak_all_64_lanes": tf / FP64_VALU_PEAK_TF,
+                   "executed_flops_per_eval_all_64_lanes": flops / S, "lane_occupancy": occ, "source": src,
+                   "note": "wavefront instructions x 64 lanes; the *_active_lanes figures multiply by the measured share of "
+                           "lanes the exec mask had switched on (SQ_THREAD_CYCLES_VALU / 64 SQ_ACTIVE_INST_VALU): what the "
+                           "hardware usefully did"}
+            if occ is not None:
+                out.update({"executed_tflops": tf * occ, "executed_frac_of_fp64_valu_peak": tf * occ / FP64_VALU_PEAK_TF,
+                            "executed_flops_per_eval": flops / S * occ})
+            else:
+                out.update({"executed_tflops": None, "executed_frac_of_fp64_valu_peak": None})
+            return out
     return {"executed_tflops": None, "executed_frac_of_fp64_valu_peak": None, "source": None}
+
+
+def qp_algorithmic_bytes(H: int) -> float:
+    """What one QP step of a device-resident solve has to move (mpc_amd/csrc/kernels_qp.hip, qp_step_kernel): the packed
+    LDL' factor in and out, the gradient, c, the structured dc/dx, the box, the last step and Lagrangian gradient in,
+    the multipliers in and out, the new step and Lagrangian gradient out."""
+    n, m = 6 * H, 12 * (H + 1)
+    tri, nz, mg = n * (n + 1) // 2, 6 * H + 3 * H * (H + 1), m + 2 * n
+    return 8.0 * (2 * tri + n + m + nz + 2 * n + 2 * n + 2 * mg + 2 * n)
+
+
+def solves_roofline(H, n_qp, solved, seconds):
+    """The solves leg against its two bounds, from the committed counter passes of its dominant kernel
+    (profiles/rNN/qp_roofline.json: FP64 wavefront instructions, HBM bytes and lane occupancy per QP step over real
+    recorded QP subproblems, and the kernel's share of the leg's GPU time from the kernel trace of a full-size solve)
+    and the LIVE number of QP steps and seconds of this run."""
+    for t, src in _profile_entries("qp_roofline.json"):
+        if t.get("horizon") != H:
+            continue
+        share = float(t["share_of_gpu_time"])
+        occ = t.get("lane_occupancy") or 1.0
+        kernel_s = seconds * share                         # the leg is one stream of kernels back to back
+        flops = float(t["executed_flops_per_qp"]) * n_qp
+        traffic = float(t["traffic_bytes_per_qp"]) * n_qp
+        tf = flops / kernel_s / 1e12
+        return {"dominant_kernel": t["kernel"], "share_of_gpu_time": share, "qp_steps": n_qp,
+                "qp_steps_per_solve": n_qp / max(solved, 1.0),
+                "kernel_seconds_estimate": kernel_s,
+                "executed_flops_per_qp_all_64_lanes": t["executed_flops_per_qp"], "lane_occupancy": t.get("lane_occupancy"),
+                "executed_tflops_all_64_lanes": tf, "executed_tflops": tf * occ,
+                "frac_of_fp64_valu_peak_all_64_lanes": tf / FP64_VALU_PEAK_TF,
+                "frac_of_fp64_valu_peak": tf * occ / FP64_VALU_PEAK_TF, "peak_tflops": FP64_VALU_PEAK_TF,
+                "whole_leg_executed_tflops": flops * occ / seconds / 1e12,
+                "whole_leg_frac_of_fp64_valu_peak": flops * occ / seconds / 1e12 / FP64_VALU_PEAK_TF,
+                "traffic_bytes_per_qp": t["traffic_bytes_per_qp"], "algorithmic_bytes_per_qp": qp_algorithmic_bytes(H),
+                "hbm_gbs": traffic / kernel_s / 1e9, "hbm_frac": traffic / kernel_s / 1e9 / HBM_PEAK_GBS,
+                "algorithmic_hbm_frac": qp_algorithmic_bytes(H) * n_qp / kernel_s / 1e9 / HBM_PEAK_GBS,
+                "bound": "neither peak: barrier-separated recurrences and an HBM-resident NNLS matrix (DESIGN.md 4.4)",
+                "source": src}
+    return None
 
 
 ALGORITHMIC_NOTE = ("full-rollout count of SURVEY.md 8(d), (1+6H)(745H+600+30(H+1)) per eval; the prefix kernel shares the "
@@ -309,7 +359,14 @@ def single_tick_latency(device, with_cpu):
     return out
 
 
-def solve_rate(ctx, mp, sample, threads, rank, world, dist, driver="resident"):
+def solve_scenarios(ctx, mp, count, rank, sweep_motion=None):
+    """The solves leg's scenarios: configs[2]'s angular-motion list, or this rank's rows of the configs[4] sweep."""
+    if sweep_motion is not None:
+        return make_sweep(mp, DeviceKinematics(ctx), rank * count, count, motion=sweep_motion)
+    return make_scenarios(mp, DeviceKinematics(ctx), count, motion="angular", cfg_id=3, goal_jitter=0.0, first=rank * count)
+
+
+def solve_rate(ctx, mp, sample, threads, rank, world, dist, driver="resident", sweep_motion=None):
     """MPC solves/s on a bounded sample (BASELINE.json's second metric): full SLSQP solves of
     angular-motion scenarios (configs[2] shape), one tick each.  Drivers (identical iterates, bit for bit):
       resident   everything on the GPU (mpc_solve_*): evaluations, BFGS update + QP, and Kraft's O(n + m) body as
@@ -336,8 +393,7 @@ def solve_rate(ctx, mp, sample, threads, rank, world, dist, driver="resident"):
     count = min(sample, ctx.max_scenarios)
     native, err, hs, bm, dt, table = None, None, None, None, 0.0, None
     try:
-        hs = make_scenarios(mp, DeviceKinematics(ctx), count, motion="angular", cfg_id=3, goal_jitter=0.0,
-                            first=rank * count)
+        hs = solve_scenarios(ctx, mp, count, rank, sweep_motion)
         if driver == "resident":
             native = ResidentSLSQP(ctx, capacity=count, lanes=1)
         else:
@@ -366,14 +422,16 @@ def solve_rate(ctx, mp, sample, threads, rank, world, dist, driver="resident"):
         if native is not None:
             native.close()
     r = bm.last
-    stats = torch.tensor([dt, float(hs.active.sum()), float(r.success.sum()), float(r.n_eval_fd), float(r.n_eval)],
-                         dtype=torch.float64, device=ctx.device)
+    stats = torch.tensor([dt, float(hs.active.sum()), float(r.success.sum()), float(r.n_eval_fd), float(r.n_eval),
+                          float(r.n_qp) if device_qp else 0.0], dtype=torch.float64, device=ctx.device)
     if dist is not None:
         mx = stats.clone()
         all_reduce(dist, mx, dist.ReduceOp.MAX)
         all_reduce(dist, stats, dist.ReduceOp.SUM)
         stats[0] = mx[0]
-    dt_all, solved, conv, nfd, nf = (float(v) for v in stats.tolist())
+    dt_all, solved, conv, nfd, nf, nqp = (float(v) for v in stats.tolist())
+    what = (f"rows of the 32x32 amplitude x phase lattice x 1,024 goal poses sweep, {sweep_motion} platform motion"
+            if sweep_motion is not None else "angular-motion scenarios")
     where = {"resident": "whole solves resident on the GPU (mpc_solve_*: Kraft's body, BFGS updates and QP subproblems "
                          "as kernels over device-side request lists), one host thread per GPU enqueuing rounds",
              "device_qp": f"BFGS updates and QP subproblems on the GPU (mpc_qp_step), SLSQP's scalar logic (libmpc_slsqp.so) "
@@ -382,7 +440,7 @@ def solve_rate(ctx, mp, sample, threads, rank, world, dist, driver="resident"):
     out = {"value": solved / dt_all, "unit": "solves/s",
            "driver": {"resident": "ResidentSLSQP", "device_qp": "DeviceQpSLSQP", "native": "NativeBatchedSLSQP"}[driver],
            "host_bound": not device_qp, "host_threads_per_gpu": threads,
-           "sample": f"{int(solved)} angular-motion scenarios ({count} per GPU), H={mp.horizon}, one tick each, "
+           "sample": f"{int(solved)} {what} ({count} per GPU), H={mp.horizon}, one tick each, "
                      f"{int(conv)} converged, {int(nfd)} eval_fd + {int(nf)} eval scenario-evals on the GPU, {where}",
            "seconds": dt_all, "mean_iterations": float(r.nit.mean()), "rounds_rank0": r.rounds,
            "rank0_core_seconds_busiest_thread": r.t_core, "rank0_seconds_serving_from_gpu": r.t_serve}
@@ -390,6 +448,9 @@ def solve_rate(ctx, mp, sample, threads, rank, world, dist, driver="resident"):
                        "converged_rows": int((table[:, 8] == 0).sum()), "early_exit_rows": int((table[:, 8] == -1).sum()),
                        "sum_abs_u0": float(np.abs(table[:, 1:7]).sum()),
                        "how": "one all_gather of every rank's [count, 9] block, inside the timed region"}
+    if driver == "resident":
+        # per GPU: every rank runs the same kernels on its own shard, so the fractions are those of one GPU
+        out["roofline"] = solves_roofline(mp.horizon, nqp / world, solved / world, dt_all)
     if device_qp:
         out["rank0_qp_subproblems_on_gpu"] = int(r.n_qp)
         out["rank0_solved_again_on_host"] = int(r.n_host_fallback)
@@ -427,19 +488,31 @@ def rehearse_launch(args, world):
         dist.init_process_group("gloo")
     if os.environ.get("MPC_BENCH_REHEARSE_FAIL_RANK") == str(rank):     # test hook: one rank dies before the gather
         sys.exit(f"rank {rank}: failing on request")
-    S = min(args.scenarios, 1000)
-    gidx = rank * S + np.arange(S)
-    local = np.stack([np.sin(gidx * (k + 1.0)) for k in range(9)], axis=1)
+    S = min(args.scenarios or 1000, 4096)
+
+    def rows_of(gidx):
+        if args.workload == "sweep":        # [A, phi, goal offset (6), goal index] of the global sweep rows: no kinematics
+            from mpc_amd.scenarios import sweep_goal_table, sweep_index, sweep_lattice
+
+            ia, ip, goal = sweep_index(gidx)
+            A, phi = sweep_lattice(args.motion)
+            return np.concatenate([A[ia][:, None], phi[ip][:, None], sweep_goal_table(args.horizon)[goal, :6],
+                                   goal[:, None].astype(float)], axis=1)
+        return np.stack([np.sin(gidx * (k + 1.0)) for k in range(9)], axis=1)
+
+    # the sweep rehearsal strides the shards over the whole lattice (rank r starts at row r * 131,072 like the real run)
+    per_rank = SWEEP_ROWS // 8 if args.workload == "sweep" else S
+    local = rows_of(rank * per_rank + np.arange(S))
     t0 = time.perf_counter()
     table = gather_result_rows(dist, local, world, rank, None)
     dt = time.perf_counter() - t0
-    want = np.stack([np.sin(np.arange(world * S) * (k + 1.0)) for k in range(9)], axis=1)
+    want = np.concatenate([rows_of(r * per_rank + np.arange(S)) for r in range(world)])
     assert np.array_equal(table, want), "gathered table is not the single-process table"
     if rank == 0:
         print(json.dumps({"metric": "launch rehearsal (no GPU, numbers mean nothing)", "value": 0.0, "unit": "evals/s",
                           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt * 1e3,
                           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
-                          "data": "synthetic", "config": {"workload": "rehearsal", "scenarios_per_gpu": S,
+                          "data": "synthetic", "config": {"workload": f"rehearsal ({args.workload})", "scenarios_per_gpu": S,
                                                           "parallelism": f"scenario-dp{world}"},
                           "solves": {"gathered": {"rows": int(table.shape[0]), "checksum": float(table.sum())},
                                      "host_threads_per_gpu": int(os.environ.get("OMP_NUM_THREADS", "0"))}}), flush=True)
@@ -453,13 +526,16 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--scenarios", type=int, default=65536, help="scenarios per GPU")
+    ap.add_argument("--scenarios", type=int, default=0, help="scenarios per GPU (default 65,536; 131,072 for the sweep)")
+    ap.add_argument("--workload", default="scenarios", choices=["scenarios", "sweep"],
+                    help="scenarios: i.i.d. draws of the scenario family (BASELINE configs[1]-[3]); sweep: configs[4], "
+                         "the 32x32 amplitude x phase lattice x 1,024 goal poses, rank r takes rows [r S, (r+1) S)")
     ap.add_argument("--horizon", type=int, default=20)
     ap.add_argument("--motion", default="linear", choices=["linear", "angular"])
     ap.add_argument("--algo", type=int, default=_ffi.ALGO_AUTO)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--solve-sample", type=int, default=65536,
-                    help="scenarios per GPU in the bounded solves/s sample (0: skip)")
+    ap.add_argument("--solve-sample", type=int, default=-1,
+                    help="scenarios per GPU in the bounded solves/s sample (0: skip; default: --scenarios)")
     ap.add_argument("--solve-workers", type=int, default=0, help="SLSQP host threads per GPU (0: host cores - 1)")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="development only: every rank uses device 0 and the process group is gloo, to walk the "
@@ -473,14 +549,20 @@ def main():
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # no launcher around us: start the ranks ourselves, before anything here touches the GPU
-        if not (args.rehearse_on_one_gpu or args.rehearse_launch) and torch.cuda.device_count() < args.gpus:
-            sys.exit(f"bench.py --gpus {args.gpus}: only {torch.cuda.device_count()} GPUs visible")
+        # (no device count here: that would bring the HIP runtime up in this process; a rank without a GPU fails cleanly)
         sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if "WORLD_SIZE" in os.environ and world != args.gpus:
         sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started {world} ranks")
     if args.rehearse_launch:
         return rehearse_launch(args, world)
+    sweep = args.workload == "sweep"
+    if not args.scenarios:
+        args.scenarios = SWEEP_ROWS // 8 if sweep else 65536
+    if args.solve_sample < 0:
+        args.solve_sample = args.scenarios
+    if sweep and world * args.scenarios > SWEEP_ROWS:
+        sys.exit(f"bench.py: the sweep has {SWEEP_ROWS} rows, {world} ranks x {args.scenarios} is more")
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -505,7 +587,10 @@ def main():
     mp = MpcParams.reference_yaml_defaults(horizon=H, algo=args.algo)
     ctx = MpcContext(mp, max_scenarios=S, device=local_rank)
     # this rank's contiguous shard of the global scenario list (rows depend only on the global index)
-    hs = make_scenarios(mp, DeviceKinematics(ctx), S, motion=args.motion, cfg_id=2, first=rank * S)
+    if sweep:
+        hs = make_sweep(mp, DeviceKinematics(ctx), rank * S, S, motion=args.motion)
+    else:
+        hs = make_scenarios(mp, DeviceKinematics(ctx), S, motion=args.motion, cfg_id=2, first=rank * S)
     sc, x = to_device(ctx, hs)
     out = EvalResult(*(torch.empty(s, dtype=torch.float64, device=ctx.device)
                        for s in ((S,), (S, mp.n), (S, mp.m), (S, mp.n, mp.m))))
@@ -555,7 +640,8 @@ def main():
         local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
         workers = args.solve_workers or max(1, min(15, host_core_budget(local_world) - 1))
         log(f"solves leg (host threads for the comparison drivers: {workers})")
-        solves = solve_rate(ctx, mp, args.solve_sample, workers, rank, world, dist)
+        solves = solve_rate(ctx, mp, args.solve_sample, workers, rank, world, dist,
+                            sweep_motion=args.motion if sweep else None)
         log("solves leg done")
 
     if rank == 0:
@@ -574,8 +660,11 @@ def main():
             "value": value, "unit": "evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"{args.motion}-platform-motion scenarios, H={H}, objective+FD gradient+dense FD "
-                                   f"constraint Jacobian, {S} scenarios per GPU resident in HBM (north_star target size)",
+            "config": {"workload": (f"sweep of platform amplitude x phase (32x32 lattice) x 1,024 goal poses (BASELINE configs[4]), "
+                                    f"{args.motion} platform motion, rows [r*{S}, (r+1)*{S}) on rank r, H={H}, objective+FD "
+                                    f"gradient+dense FD constraint Jacobian, resident in HBM" if sweep else
+                                    f"{args.motion}-platform-motion scenarios, H={H}, objective+FD gradient+dense FD "
+                                    f"constraint Jacobian, {S} scenarios per GPU resident in HBM (north_star target size)"),
                        "horizon": H, "scenarios_per_gpu": S, "n_vars": mp.n, "n_constraints": mp.m,
                        "algo": algo_name,
                        "parallelism": f"scenario-dp{world}"},
@@ -634,7 +723,7 @@ def main():
             line["evals_per_s_4096_scenarios"] = 4096 / (e0.elapsed_time(e1) / args.steps * 1e-3)
         if solves is not None:
             line["solves"] = solves
-            if extras and world == 1 and "error" not in solves:
+            if extras and world == 1 and not sweep and "error" not in solves:
                 try:        # 4,096 scenarios (configs[1]'s batch size) through the same driver: latency-bound rounds
                     line["solves_4096_scenarios"] = solve_rate(ctx, mp, 4096, 1, 0, 1, None)
                 except Exception as exc:  # noqa: BLE001 - a comparison figure, not the metric
@@ -652,9 +741,10 @@ def main():
                     line["solves_scipy_core_pool"] = pool_solve_rate(ctx, mp, 32, workers)
                 except Exception as exc:  # noqa: BLE001 - a comparison figure, not the metric
                     line["solves_scipy_core_pool"] = {"error": repr(exc)}
-        if extras and world == 1:
+        # rank 0 alone, after the timed legs, also when N > 1: the other ranks wait at the closing barrier
+        if extras and not sweep:
             line["single_tick_default_yaml"] = single_tick_latency(local_rank, not args.no_cpu_baseline)
-        if extras and not args.no_cpu_baseline and world == 1:
+        if extras and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(mp, hs)
             line["speedup_vs_cpu_core"] = value / world / line["cpu_baseline"]["value"]
         print(json.dumps(line), flush=True)

@@ -145,6 +145,75 @@ def make_scenarios(params: MpcParams, kin, count: int, motion: str = "linear", c
     return hs
 
 
+SWEEP_GRID = 32            # amplitude x phase lattice, 32 x 32 cells
+SWEEP_GOALS = 1024         # goal poses per lattice cell
+SWEEP_ROWS = SWEEP_GRID * SWEEP_GRID * SWEEP_GOALS     # 1,048,576 = BASELINE configs[4]
+SWEEP_CFG_ID = 5
+
+
+def sweep_goal_table(horizon: int, goal_jitter: float = 0.05) -> np.ndarray:
+    """The seeded table of the sweep's 1,024 goal poses, [1024, 6 + 6H]: columns 0..5 the offset of the goal pose
+    from the tip pose (U(-goal_jitter, goal_jitter), mpc_action_server.py:77 is the nominal zero offset), the
+    rest the offset of the evaluation point / SLSQP start from the damped-least-squares guess (U(-0.05, 0.05))."""
+    rng = np.random.default_rng(BASE_SEED + SWEEP_CFG_ID)
+    U = rng.random((SWEEP_GOALS, 6 + 6 * horizon))
+    U[:, :6] = (U[:, :6] * 2.0 - 1.0) * goal_jitter
+    U[:, 6:] = U[:, 6:] * 0.1 - 0.05
+    return U
+
+
+def sweep_lattice(motion: str):
+    """Cell centres of the 32 x 32 amplitude x phase lattice over the ranges of SURVEY.md §8(d): A in 0.05..0.30 m
+    (prismatic platform joint; nominal 0.2, simulate_platform_motion.py:17) or 5..30 deg (revolute; nominal 20,
+    :23), phi in 0..2 pi."""
+    c = (np.arange(SWEEP_GRID) + 0.5) / SWEEP_GRID
+    A = (0.05 + 0.25 * c) if motion == "linear" else np.radians(5.0 + 25.0 * c)
+    return A, 2.0 * np.pi * c
+
+
+def sweep_index(rows: np.ndarray):
+    """Global sweep row -> (amplitude index, phase index, goal index): row = (ia * 32 + ip) * 1024 + goal."""
+    rows = np.asarray(rows, dtype=np.int64)
+    cell, goal = rows // SWEEP_GOALS, rows % SWEEP_GOALS
+    return cell // SWEEP_GRID, cell % SWEEP_GRID, goal
+
+
+def make_sweep(params: MpcParams, kin, first: int, count: int, motion: str = "linear",
+               with_prev: bool = False, goal_jitter: float = 0.05) -> HostScenarios:
+    """Rows ``first .. first+count-1`` of BASELINE configs[4]: the product of a 32 x 32 lattice of platform
+    amplitude x phase (the motion family of tests/simulate_platform_motion.py:17,23,42-59) with 1,024 goal poses,
+    1,048,576 rows in all, the arm at the SRDF start pose of the motion (mpc.srdf:16-31).  Global row i is lattice
+    cell i // 1024 (amplitude index slowest) and goal pose i % 1024, whatever shard it is made in: rank r of an
+    8-GPU run makes rows [131072 r, 131072 (r+1))."""
+    if motion not in ("linear", "angular"):
+        raise ValueError("motion must be 'linear' or 'angular'")
+    if first < 0 or count < 0 or first + count > SWEEP_ROWS:
+        raise ValueError(f"the sweep has rows 0..{SWEEP_ROWS - 1}")
+    H = params.horizon
+    ia, ip, goal = sweep_index(first + np.arange(count))
+    A_axis, phi_axis = sweep_lattice(motion)
+    A, phi = A_axis[ia], phi_axis[ip]
+    table = sweep_goal_table(H, goal_jitter)[goal]
+    q0 = np.tile(Q_LINEAR_READY if motion == "linear" else Q_ANGULAR_READY, (count, 1))
+    base = platform_state(motion, A, phi)
+    ee0 = world_ee_pose(np.asarray(kin.fk(q0)), base)
+    p0, o0 = ee0[:, 0:3], ee0[:, 3:6]
+    state0 = np.concatenate([q0, np.zeros((count, 6)), p0, o0], axis=1)
+    target = np.concatenate([p0, o0], axis=1) + table[:, :6]
+    base_traj = np.asarray(kin.predict_base_dynamic(base))
+    Jc = np.asarray(kin.jacobian(q0)).reshape(count, 36)
+    u_init = dls_guess(Jc, base, p0)
+    lim = np.tile(np.asarray(params.v_lim), H)
+    x = np.clip(np.tile(u_init, (1, H)) + table[:, 6:], -lim, lim)
+    active = ~((np.linalg.norm(base[:, 6:9], axis=1) < 0.01) & (np.linalg.norm(base[:, 9:12], axis=1) < 0.01))
+    u_prev = x[:, :6].copy() if with_prev else None
+    has_prev = np.ones(count, dtype=np.uint8) if with_prev else None
+    hs = HostScenarios(motion, q0, base, state0, target, base_traj, Jc, np.ascontiguousarray(x), u_init,
+                       u_prev, has_prev, active)
+    hs.amplitude, hs.phase, hs.goal = A, phi, goal
+    return hs
+
+
 class DeviceKinematics:
     """``kin`` backend running on the GPU through libmpc_amd (MpcContext)."""
 

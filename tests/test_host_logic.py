@@ -57,6 +57,42 @@ def test_scenarios_are_shard_stable_and_in_bounds():
     assert np.all(np.abs(full.base[:, 6]) <= 0.30 * w + 1e-12) and np.all(full.base[:, [1, 2, 7, 8]] == 0)
 
 
+def test_sweep_is_the_product_of_the_lattice_and_the_goal_table():
+    """BASELINE configs[4]: global row i = (amplitude ia, phase ip, goal j) with i = (ia*32 + ip)*1024 + j, whatever
+    shard it is made in; ranges of SURVEY.md 8(d) (simulate_platform_motion.py:17,23,42-59); arm at the SRDF pose."""
+    from mpc_amd.scenarios import (Q_ANGULAR_READY, SWEEP_ROWS, make_sweep, sweep_goal_table, sweep_index, sweep_lattice)
+    from oracle.oracle import OracleKinematics
+    from helpers import oracle_for
+
+    mp = params_for(20)
+    kin = OracleKinematics(oracle_for(mp))
+    assert SWEEP_ROWS == 1 << 20
+    first = 5 * 32 * 1024 + 7 * 1024 - 9                      # straddles the cells (5, 6) and (5, 7)
+    full = make_sweep(mp, kin, first, 40, motion="angular")
+    part = make_sweep(mp, kin, first + 25, 15, motion="angular")
+    for name in ("x", "state0", "target", "base_traj", "Jc", "base", "active"):
+        np.testing.assert_array_equal(getattr(full, name)[25:], getattr(part, name))
+    ia, ip, goal = sweep_index(first + np.arange(40))
+    assert (ia == 5).all() and list(ip[:9]) == [6] * 9 and list(ip[9:]) == [7] * 31 and goal[9] == 0 and goal[8] == 1023
+    A, phi = sweep_lattice("angular")
+    assert np.radians(5.0) < A[0] < A[-1] < np.radians(30.0) and 0 < phi[0] < phi[-1] < 2 * np.pi and len(A) == len(phi) == 32
+    w = 2 * np.pi * 0.1
+    np.testing.assert_array_equal(full.base[:, 5], A[ia] * np.sin(phi[ip]))
+    np.testing.assert_array_equal(full.base[:, 11], A[ia] * w * np.cos(phi[ip]))
+    np.testing.assert_array_equal(full.q0, np.tile(Q_ANGULAR_READY, (40, 1)))
+    # the same goal (offset from the tip pose) in two different lattice cells
+    other = make_sweep(mp, kin, 17 * 32 * 1024 + 3 * 1024 + int(goal[0]), 1, motion="angular")
+    tab = sweep_goal_table(20)
+    np.testing.assert_allclose(other.target[0] - other.state0[0, 12:18], tab[goal[0], :6], rtol=0, atol=1e-15)
+    np.testing.assert_allclose(full.target[0] - full.state0[0, 12:18], tab[goal[0], :6], rtol=0, atol=1e-15)
+    lin = make_sweep(mp, kin, SWEEP_ROWS - 3, 3, motion="linear")
+    Al, _ = sweep_lattice("linear")
+    assert 0.05 < Al[0] < Al[-1] < 0.30 and np.all(lin.base[:, [1, 2, 3, 4, 5, 7, 8]] == 0)
+    assert np.all(np.abs(lin.x) <= np.tile(np.asarray(mp.v_lim), 20))
+    with pytest.raises(ValueError):
+        make_sweep(mp, kin, SWEEP_ROWS - 3, 4)
+
+
 def test_batched_kinematic_predictor_equals_per_controller_predictor():
     """Rows of the batched predictor == one KinematicBasePredictor per controller, bit for bit, over ticks on
     which only some controllers predict (the others took the early exit and keep their filter state)."""
