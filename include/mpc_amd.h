@@ -224,7 +224,7 @@ int mpc_qp_step(mpc_ctx *ctx, int count, int rows, const int32_t *index, const i
  * (SLSQP:427-456, called from MPC:188-200) for sc->count problems at once, with nothing but an "unfinished" count
  * crossing PCIe between the start point going in and the solutions coming out.  Per round and problem: one call of
  * Kraft's SLSQP body (merit function, line search, convergence tests: the text of mpc_amd/csrc/slsqp_body.inc, the same
- * file the host core of libmpc_slsqp.so is compiled from) as a one-thread-per-problem kernel, which sorts the
+ * file the host core of libmpc_slsqp.so is compiled from) as a one-wavefront-per-problem kernel, which sorts the
  * unfinished problems into three device-side request lists; then f and c (mpc_eval), grad f and the structured dc/dx
  * (mpc_eval_fd_nz) and the BFGS update + QP (mpc_qp_step) for the problems on each list, all reading the lists and
  * their lengths from device memory.  Iterates, exit modes and iteration counts are those of the host drivers, bit for bit.
@@ -236,7 +236,10 @@ int mpc_qp_step(mpc_ctx *ctx, int count, int rows, const int32_t *index, const i
  *   mpc_solve_rounds: enqueues `rounds` rounds.  `bound` >= the number of unfinished problems sizes the grids (pass
  *       sc->count, or the count a previous call reported).  After the last round the number of problems that were
  *       still unfinished in it is copied to *unfinished (device or pinned host memory, may be NULL) on the stream;
- *       0 means every problem has stopped.  Rounds after that are harmless no-ops.  A problem whose linearisation
+ *       0 means every problem has stopped; with bound == 0 nothing is launched but that copy.  -1 means a round met
+ *       more requests than `bound` sized its grids for (problems were left out: the solve is void, begin again).
+ *       If a launch fails part-way the call returns MPC_ERR_HIP and the workspace is forgotten: further rounds and
+ *       mpc_solve_result are refused until mpc_solve_begin has run again.  A problem whose linearisation
  *       is inconsistent stops with status 104 (solve it again with the host driver, include/mpc_slsqp.h).
  *   mpc_solve_result: x [N][n], fun [N], nit [N], status [N] (SLSQP's exit mode, 0 = converged) and, if non-NULL,
  *       stats[4] = {mpc_eval requests, mpc_eval_fd_nz requests, QP steps, unfinished in the last round} (device).

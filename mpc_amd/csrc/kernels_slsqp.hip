@@ -1,4 +1,4 @@
-// Whole SLSQP solves resident on the device: Kraft's O(n + m) body as a one-thread-per-problem kernel.
+// Whole SLSQP solves resident on the device: Kraft's O(n + m) body as a one-wavefront-per-problem kernel.
 //
 // scipy's driver (_slsqp_py.py:427-456) calls the compiled core once per "round": the core returns asking for
 // f and c (mode 1), for grad f and dc/dx (mode -1), or it is done.  mpc_amd/csrc/slsqp_core.c restates that core
@@ -13,41 +13,68 @@
 #include <cmath>
 
 #include "mpc_kernels.hpp"
+#include "lsq_wave.hpp"
 #include "slsqp_core.h"
 
 namespace {
 
 #define MAX(a, b) ((a) > (b) ? (a) : (b))
 
-// the BLAS-1 helpers of slsqp_core.c (same operation order; ddot's five-fold unrolling there adds its terms left to
-// right, i.e. in this order)
-__device__ __forceinline__ double ddot_sl(int n, const double *__restrict__ dx, int, const double *__restrict__ dy, int)
+#if defined(__HIP_DEVICE_COMPILE__)      // (lsq_wave.hpp exists in the device pass only)
+// The helpers of slsqp_core.c for ONE WAVEFRONT that runs the body on one problem: all 64 lanes execute the body's
+// text with the same scalars; the vectors live in LDS, entry i is the business of lane i % 64, and every ordered sum
+// (ddot's five-fold unrolling on the host adds its terms left to right: the same chain) is one chain of additions in
+// the order of the serial text, run by lsq_wave.hpp's ordered_sum_from at the FP64 pipeline's latency instead of one
+// LDS round trip per term: the terms are formed by the lanes, 128 at a time.
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
+__device__ __forceinline__ void wave_sync() { lsqwave::wave_sync(); }
+
+// t + term(0) + term(1) + ... + term(count - 1), in that order.  A block of fewer than 128 terms sits at the END of
+// the 128 slots and the chain is entered at its first term: nothing is added that the serial text does not add.
+template <class Term>
+__device__ __forceinline__ double wave_ordered_sum(double t, int count, Term term)
 {
-    double t = 0.0;
-#pragma unroll 8
-    for (int i = 0; i < n; ++i) t = t + dx[i] * dy[i];
+    const int c = lane_id() & 15;
+    wave_sync();                                   // the vectors the terms are formed from were written by other lanes
+    for (int base = 0; base < count; base += 128) {
+        const int k = count - base < 128 ? count - base : 128, pad = 128 - k;
+        double P[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const int slot = 16 * r + c;
+            P[r] = slot >= pad ? term(base + slot - pad) : 0.0;
+        }
+        t = lsqwave::ordered_sum_from(t, P, pad);
+    }
     return t;
 }
-__device__ __forceinline__ void daxpy_sl(int n, double da, const double *__restrict__ dx, int, double *__restrict__ dy, int)
+
+__device__ __forceinline__ double ddot_sl(int n, const double *dx, int, const double *dy, int)
+{
+    return wave_ordered_sum(0.0, n, [&](int i) { return dx[i] * dy[i]; });
+}
+__device__ __forceinline__ void daxpy_sl(int n, double da, const double *dx, int, double *dy, int)
 {
     if (n <= 0 || da == 0.0) return;
-#pragma unroll 8
-    for (int i = 0; i < n; ++i) dy[i] = dy[i] + da * dx[i];
+    for (int i = lane_id(); i < n; i += 64) dy[i] = dy[i] + da * dx[i];
+    wave_sync();
 }
-__device__ __forceinline__ void dcopy_(int n, const double *__restrict__ dx, int, double *__restrict__ dy, int)
+__device__ __forceinline__ void dcopy_(int n, const double *dx, int, double *dy, int)
 {
-#pragma unroll 8
-    for (int i = 0; i < n; ++i) dy[i] = dx[i];
+    for (int i = lane_id(); i < n; i += 64) dy[i] = dx[i];
+    wave_sync();
 }
 __device__ __forceinline__ void dscal_sl(int n, double da, double *dx, int)
 {
-#pragma unroll 8
-    for (int i = 0; i < n; ++i) dx[i] = da * dx[i];
+    for (int i = lane_id(); i < n; i += 64) dx[i] = da * dx[i];
+    wave_sync();
 }
+// the scaled sum of squares is a recurrence with a branch per term: every lane runs it on the same entries
 __device__ __forceinline__ double dnrm2_(int n, const double *dx, int)
 {
     double scale = 0.0, ssq = 1.0;
     if (n < 1) return 0.0;
+    wave_sync();
     for (int i = 0; i < n; ++i) {
         if (dx[i] != 0.0) {
             const double ax = fabs(dx[i]);
@@ -57,20 +84,48 @@ __device__ __forceinline__ double dnrm2_(int n, const double *dx, int)
     }
     return scale * sqrt(ssq);
 }
+// the loops of the body over the constraints (slsqp_core.c has the serial forms)
+__device__ __forceinline__ void sl_fill(int n, double *x, double v)
+{
+    for (int i = lane_id(); i < n; i += 64) x[i] = v;
+    wave_sync();
+}
+__device__ __forceinline__ double sl_sum_infeas(int m, int meq, const double *c, double t)
+{
+    return wave_ordered_sum(t, m, [&](int j) {
+        const double h = (j < meq) ? c[j] : 0.0;
+        return MAX(-c[j], h);
+    });
+}
+__device__ __forceinline__ double sl_sum_mu_infeas(int m, int meq, const double *mu, const double *c, double t)
+{
+    return wave_ordered_sum(t, m, [&](int j) {
+        const double h = (j < meq) ? c[j] : 0.0;
+        return mu[j] * MAX(-c[j], h);
+    });
+}
+__device__ __forceinline__ double sl_sum_abs_prod(int m, const double *r, const double *c, double t)
+{
+    return wave_ordered_sum(t, m, [&](int j) { return fabs(r[j]) * fabs(c[j]); });
+}
+__device__ __forceinline__ void sl_mu_update(int m, const double *r, double *mu)
+{
+    for (int j = lane_id(); j < m; j += 64) {
+        const double h = fabs(r[j]);
+        mu[j] = MAX(h, (mu[j] + h) / 2.0);
+    }
+    wave_sync();
+}
 
-// (the vectors are distinct arrays: __restrict__ lets the compiler issue a loop's loads ahead of its stores)
-__device__ __forceinline__ void slsqp_body_device(int m, int meq, int la, int n, double *__restrict__ x,
-                                                  const double *__restrict__ xl, const double *__restrict__ xu, double f,
-                                                  const double *__restrict__ c, const double *__restrict__ g, double *a,
-                                                  double *acc, int *iter, int *mode, const double *__restrict__ r, double *l,
-                                                  double *__restrict__ x0, double *__restrict__ mu, double *__restrict__ s,
-                                                  double *__restrict__ u, double *__restrict__ v, double *w, int *iw,
-                                                  slsqp_state *S)
+// (no __restrict__ here: the lanes of the wavefront read what other lanes wrote)
+__device__ __forceinline__ void slsqp_body_device(int m, int meq, int la, int n, double *x, const double *xl, const double *xu,
+                                                  double f, const double *c, const double *g, double *a, double *acc, int *iter,
+                                                  int *mode, const double *r, double *l, double *x0, double *mu, double *s,
+                                                  double *u, double *v, double *w, int *iw, slsqp_state *S)
 #define SLSQP_BODY_FULL 0
-#define SLSQP_BODY_UNROLL _Pragma("unroll 8")
 #include "slsqp_body.inc"
-#undef SLSQP_BODY_UNROLL
 #undef SLSQP_BODY_FULL
+#endif  // __HIP_DEVICE_COMPILE__
 
 }  // namespace
 
@@ -106,6 +161,8 @@ using mpck::SolveWorkspace;
 
 static_assert(sizeof(slsqp_state) % sizeof(double) == 0, "slsqp_state rows are carved from a double array");
 
+constexpr int kTotals = 24, kOverflow = 27;      // places in W.counters beyond the three slots of eight
+
 // x0 clipped into the box (_slsqp_py.py:268), the state of a first call (mode 0), the box itself (MPC:420-430)
 __global__ void solve_begin_kernel(const mpc_params P, SolveWorkspace W, int count, const double *__restrict__ x0, double acc,
                                    int maxiter)
@@ -119,9 +176,9 @@ __global__ void solve_begin_kernel(const mpc_params P, SolveWorkspace W, int cou
         W.lb[idx] = -lim;
         W.ub[idx] = lim;
     }
-    // lists of "round -1" (slot 0): every problem is waiting for its first call of the body
+    // lists of "round -1" (counter slot 0): every problem is waiting for its first call of the body
     // (the seed list is not a round of f requests: the running total starts at -count, see solve_body_kernel)
-    if (idx < 32) W.counters[idx] = (idx == 0 || idx == 3) ? count : (idx == 16 ? -count : 0);
+    if (idx < 32) W.counters[idx] = (idx == 0 || idx == 3) ? count : (idx == kTotals ? -count : 0);
     if (idx < (size_t)count) W.LIST_F[0][idx] = (int32_t)idx;
     if (idx >= (size_t)count * n) return;
     const int i = (int)(idx % n);
@@ -148,24 +205,34 @@ __global__ void solve_begin_kernel(const mpc_params P, SolveWorkspace W, int cou
 
 // One call of the body for every unfinished problem, one wavefront per problem: the problems are those on the
 // previous round's three request lists (slot `old` of the double-buffered lists and counters; they were served since),
-// the vectors the body reads are staged in LDS with coalesced loads, the first lane runs the body on them, the team
+// the vectors the body reads are staged in LDS with coalesced loads, the wavefront runs the body on them, the team
 // writes back what it changed.  What the problem asks for next goes to the new slot's lists.
+// The request lists alternate between two buffers (round r reads buffer r % 2 and writes the other); their counters
+// rotate through THREE slots, so that a round can clear the slot of the round after it and no memset sits between
+// the rounds: round r reads slot r % 3, fills slot (r + 1) % 3 and zeroes slot (r + 2) % 3, which nothing has read
+// since round r - 1's body.
 // counters, per slot s at [8 s ..]: +0 f requests, +1 derivative requests, +2 QP requests, +3 their total (= problems
-// still unfinished; written by solve_count_kernel), +4 the QP kernel's work-queue head (the caller zeroes the new slot
-// before the launch); [16..18] running totals of the three kinds over every round up to and including the old slot's
-// (the first workgroup adds the old slot's lengths).  One atomic per problem and round (its slot in a list): every problem of a lock-step round increments the same word,
-// and L2 serialises them.
+// still unfinished, or -1 if a round met more requests than its grid was sized for; written by solve_count_kernel),
+// +4 the QP kernel's work-queue head; [kTotals ..] running totals of the three kinds over every round up to and
+// including the old slot's (the first workgroup adds the old slot's lengths), [kOverflow] the sticky flag "a round's
+// `bound` was smaller than its lists".  One atomic per kind and workgroup (every problem of a lock-step round would
+// increment the same word, and L2 serialises them).
 constexpr int kBodyWaves = 4;      // problems per workgroup of solve_body_kernel, one wavefront each (fewer if LDS is short)
 
-__global__ __launch_bounds__(64 * kBodyWaves) void solve_body_kernel(int H, SolveWorkspace W, int old)
+__global__ __launch_bounds__(64 * kBodyWaves) void solve_body_kernel(int H, SolveWorkspace W, int old, int cs_old, int cs_new,
+                                                                     int cs_next)
 {
     extern __shared__ double body_lds[];
     __shared__ int ask[kBodyWaves];          // what each wavefront's problem asks for: 0 f, 1 derivatives, 2 QP, -1 nothing
     __shared__ int first[3];                 // first list position of this workgroup's requests, per kind
-    const int32_t *co = W.counters + 8 * old;
-    int32_t *cn = W.counters + 8 * (1 - old);
+    const int32_t *co = W.counters + 8 * cs_old;
+    int32_t *cn = W.counters + 8 * cs_new;
     const int cF = co[0], cG = co[1], cQ = co[2];
-    if (blockIdx.x == 0 && threadIdx.x < 3) W.counters[16 + threadIdx.x] += co[threadIdx.x];   // the round just served
+    if (blockIdx.x == 0) {
+        if (threadIdx.x < 3) W.counters[kTotals + threadIdx.x] += co[threadIdx.x];   // the round just served
+        if (threadIdx.x < 8) W.counters[8 * cs_next + threadIdx.x] = 0;               // the next round's slot
+        if (threadIdx.x == 8 && (long long)cF + cG + cQ > (long long)gridDim.x * (blockDim.x >> 6)) W.counters[kOverflow] = 1;
+    }
     const int n = 6 * H, m = 12 * (H + 1), mg = m + 2 * n, lane = (int)(threadIdx.x & 63u), wave = (int)(threadIdx.x >> 6);
     const int waves = (int)(blockDim.x >> 6);
     int k = (int)blockIdx.x * waves + wave, p = -1;
@@ -205,7 +272,9 @@ __global__ __launch_bounds__(64 * kBodyWaves) void solve_body_kernel(int H, Solv
         }
     }
     __syncthreads();
-    if (lane == 0) {
+    {
+        // the whole wavefront runs the body (same scalars in every lane, the vectors shared out); its first lane files
+        // the scalars away
         int kind = -1;
         if (live) {
             int mode = W.MODE[p];
@@ -213,20 +282,22 @@ __global__ __launch_bounds__(64 * kBodyWaves) void solve_body_kernel(int H, Solv
             if (mode == MPC_SLSQP_MODE_QP) S.qp_mode = W.QPMODE[p];
             int iter = W.ITER[p];
             double acc = W.ACC[p];
+#if defined(__HIP_DEVICE_COMPILE__)
             slsqp_body_device(m, 0, m, n, x, W.lb, W.ub, W.F[p], c, g, nullptr, &acc, &iter, &mode, r, nullptr, x0, mu, s, u, v,
                               nullptr, nullptr, &S);
-            W.ST[p] = S;
-            W.ITER[p] = iter;
-            W.ACC[p] = acc;
-            W.MODE[p] = mode;                                       // not 1, -1 or QP: finished, this is the exit mode
+#endif
             if (mode == 1) kind = 0;
             else if (mode == -1) kind = 1;
-            else if (mode == MPC_SLSQP_MODE_QP) {
-                kind = 2;
-                W.QPFLAGS[p] = (S.qp_reset ? 1 : 0) | (S.qp_bfgs ? 2 : 0);
+            else if (mode == MPC_SLSQP_MODE_QP) kind = 2;
+            if (lane == 0) {
+                W.ST[p] = S;
+                W.ITER[p] = iter;
+                W.ACC[p] = acc;
+                W.MODE[p] = mode;                                   // not 1, -1 or QP: finished, this is the exit mode
+                if (kind == 2) W.QPFLAGS[p] = (S.qp_reset ? 1 : 0) | (S.qp_bfgs ? 2 : 0);
             }
         }
-        ask[wave] = kind;
+        if (lane == 0) ask[wave] = kind;
     }
     __syncthreads();
     // one atomic per kind and WORKGROUP reserves the list positions of its requests (every problem of a lock-step round
@@ -268,7 +339,7 @@ __global__ void solve_result_kernel(int H, SolveWorkspace W, int count, int slot
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx < 4 && stats != nullptr) {     // the latest slot's requests have been served but not yet added to the totals
         const int32_t *c = W.counters + 8 * slot;
-        stats[idx] = idx < 3 ? W.counters[16 + idx] + c[idx] : c[0] + c[1] + c[2];
+        stats[idx] = idx < 3 ? W.counters[kTotals + idx] + c[idx] : (W.counters[kOverflow] ? -1 : c[0] + c[1] + c[2]);
     }
     if (idx >= (size_t)count * n) return;
     x[idx] = W.X[idx];
@@ -280,8 +351,12 @@ __global__ void solve_result_kernel(int H, SolveWorkspace W, int count, int slot
     }
 }
 
-// unfinished problems of a round = the lengths of its three request lists
-__global__ void solve_count_kernel(int32_t *__restrict__ c) { c[3] = c[0] + c[1] + c[2]; }
+// unfinished problems of a round = the lengths of its three request lists; -1 once a round was launched with a grid
+// smaller than its lists (problems were left out of it: the solve is void)
+__global__ void solve_count_kernel(int32_t *__restrict__ c, const int32_t *__restrict__ overflow)
+{
+    c[3] = *overflow ? -1 : c[0] + c[1] + c[2];
+}
 
 }  // namespace
 
@@ -298,10 +373,10 @@ hipError_t launch_solve_begin(const mpc_params &P, const SolveWorkspace &W, int 
     return hipGetLastError();
 }
 
-hipError_t launch_solve_body(int H, const SolveWorkspace &W, int bound, int old_slot, hipStream_t stream)
+hipError_t launch_solve_body(int H, const SolveWorkspace &W, int bound, int round, hipStream_t stream)
 {
-    hipError_t e = hipMemsetAsync(W.counters + 8 * (1 - old_slot), 0, 8 * sizeof(int32_t), stream);
-    if (e != hipSuccess || bound <= 0) return e;
+    if (bound <= 0) return hipSuccess;
+    hipError_t e = hipSuccess;
     const size_t per = sizeof(double) * (size_t)(6 * 6 * H + 3 * 12 * (H + 1));
     int waves = (int)((size_t)150 * 1024 / per);
     waves = waves < 1 ? 1 : (waves > kBodyWaves ? kBodyWaves : waves);
@@ -312,7 +387,7 @@ hipError_t launch_solve_body(int H, const SolveWorkspace &W, int bound, int old_
         if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL(solve_body_kernel, dim3((unsigned)((bound + waves - 1) / waves)), dim3(64 * waves), lds, stream, H, W,
-                       old_slot);
+                       round & 1, round % 3, (round + 1) % 3, (round + 2) % 3);
     return hipGetLastError();
 }
 
@@ -327,7 +402,7 @@ hipError_t launch_solve_result(int H, const SolveWorkspace &W, int count, int sl
 
 hipError_t launch_solve_count(const SolveWorkspace &W, int slot, hipStream_t stream)
 {
-    hipLaunchKernelGGL(solve_count_kernel, dim3(1), dim3(1), 0, stream, W.counters + 8 * slot);
+    hipLaunchKernelGGL(solve_count_kernel, dim3(1), dim3(1), 0, stream, W.counters + 8 * slot, W.counters + kOverflow);
     return hipGetLastError();
 }
 

@@ -26,8 +26,8 @@ struct mpc_ctx {
     double *d_qp_work = nullptr;  // mpc_qp_solve: workspace of the resident workgroups (allocated on first use)
     int *d_qp_iwork = nullptr;
     int qp_teams = 0;
-    const void *solve_ws = nullptr;   // mpc_solve_*: the workspace mpc_solve_begin set up, and which of its two
-    int solve_slot = 0;               // list/counter slots holds the latest round's requests
+    const void *solve_ws = nullptr;   // mpc_solve_*: the workspace mpc_solve_begin set up, and how many rounds have run on
+    int solve_round = 0;              // it: round r's requests are in list buffer (r + 1) % 2, counter slot (r + 1) % 3
     double *d_static = nullptr;   // this device's copy of the file-scope `scratch` array (mpc_eval_fd_static)
     char err[512] = {0};
 };
@@ -526,7 +526,7 @@ int mpc_solve_begin(mpc_ctx *ctx, const mpc_scenarios *sc, const double *x0, dou
     // mode 0 on entry: f, c, grad f and dc/dx at the (clipped) start point for everyone (SLSQP:419-425)
     MPC_HIP(ctx, mpck::launch_prefix_nz(ctx->params, ctx->d_decay, *sc, W.XE, W.F, W.G, W.C, W.NZ, st));
     ctx->solve_ws = ws;
-    ctx->solve_slot = 0;
+    ctx->solve_round = 0;
     return MPC_OK;
 }
 
@@ -546,27 +546,38 @@ int mpc_solve_rounds(mpc_ctx *ctx, const mpc_scenarios *sc, void *ws, int rows, 
     hipStream_t st = static_cast<hipStream_t>(stream);
     MPC_HIP(ctx, hipSetDevice(ctx->device));
     const mpck::SolveWorkspace W = mpck::carve_solve_workspace(ws, ctx->horizon, rows);
-    for (int r = 0; r < rounds; ++r) {
-        const int old = ctx->solve_slot, cur = 1 - old;
-        MPC_HIP(ctx, mpck::launch_solve_body(ctx->horizon, W, bound, old, st));
-        ctx->solve_slot = cur;
-        if (bound == 0) continue;
+    // A launch that fails part-way leaves the device lists and this context's round count out of step: the workspace
+    // is then forgotten, and further calls are refused until mpc_solve_begin has run again.
+#define MPC_SOLVE_HIP(call)                                      \
+    do {                                                         \
+        hipError_t e_ = (call);                                  \
+        if (e_ != hipSuccess) {                                  \
+            ctx->solve_ws = nullptr;                             \
+            return hip_fail(ctx, e_, #call);                     \
+        }                                                        \
+    } while (0)
+    for (int r = 0; r < rounds && bound > 0; ++r) {     // bound == 0: nothing is unfinished, the state stays as it is
+        const int round = ctx->solve_round, cur = (round + 1) & 1, cs = (round + 1) % 3;
+        MPC_SOLVE_HIP(mpck::launch_solve_body(ctx->horizon, W, bound, round, st));
+        ctx->solve_round = round + 1;
         mpck::RowList lf, lg, lq;
-        lf.list = W.LIST_F[cur]; lf.count = W.counters + 8 * cur + 0; lf.bound = bound;
-        lg.list = W.LIST_G[cur]; lg.count = W.counters + 8 * cur + 1; lg.bound = bound;
-        lq.list = W.LIST_Q[cur]; lq.count = W.counters + 8 * cur + 2; lq.bound = bound;
-        lq.head = W.counters + 8 * cur + 4;
+        lf.list = W.LIST_F[cur]; lf.count = W.counters + 8 * cs + 0; lf.bound = bound;
+        lg.list = W.LIST_G[cur]; lg.count = W.counters + 8 * cs + 1; lg.bound = bound;
+        lq.list = W.LIST_Q[cur]; lq.count = W.counters + 8 * cs + 2; lq.bound = bound;
+        lq.head = W.counters + 8 * cs + 4;
         // f and c where the line search asked for them (SLSQP:434-436)
-        MPC_HIP(ctx, mpck::launch_prefix_rows(ctx->params, ctx->d_decay, *sc, W.XE, W.F, nullptr, W.C, nullptr, lf, st));
+        MPC_SOLVE_HIP(mpck::launch_prefix_rows(ctx->params, ctx->d_decay, *sc, W.XE, W.F, nullptr, W.C, nullptr, lf, st));
         // grad f and dc/dx at the accepted point (SLSQP:438-440); f and c there are already in place
-        MPC_HIP(ctx, mpck::launch_prefix_rows(ctx->params, ctx->d_decay, *sc, W.XE, W.F, W.G, nullptr, W.NZ, lg, st));
+        MPC_SOLVE_HIP(mpck::launch_prefix_rows(ctx->params, ctx->d_decay, *sc, W.XE, W.F, W.G, nullptr, W.NZ, lg, st));
         // BFGS update + QP of the problems that start a major iteration
-        MPC_HIP(ctx, mpck::launch_qp_step_rows(ctx->horizon, ctx->qp_teams, rows, lq, W.QPFLAGS, W.LO, W.HI, W.S, W.L, W.G, W.C, W.NZ,
-                                               W.RM, W.V, W.QPMODE, ctx->d_qp_work, ctx->d_qp_iwork, st));
+        MPC_SOLVE_HIP(mpck::launch_qp_step_rows(ctx->horizon, ctx->qp_teams, rows, lq, W.QPFLAGS, W.LO, W.HI, W.S, W.L, W.G, W.C,
+                                                W.NZ, W.RM, W.V, W.QPMODE, ctx->d_qp_work, ctx->d_qp_iwork, st));
     }
-    MPC_HIP(ctx, mpck::launch_solve_count(W, ctx->solve_slot, st));
+    const int slot = ctx->solve_round % 3;
+    MPC_SOLVE_HIP(mpck::launch_solve_count(W, slot, st));
     if (unfinished)
-        MPC_HIP(ctx, hipMemcpyAsync(unfinished, W.counters + 8 * ctx->solve_slot + 3, sizeof(int32_t), hipMemcpyDefault, st));
+        MPC_SOLVE_HIP(hipMemcpyAsync(unfinished, W.counters + 8 * slot + 3, sizeof(int32_t), hipMemcpyDefault, st));
+#undef MPC_SOLVE_HIP
     return MPC_OK;
 }
 
@@ -580,7 +591,7 @@ int mpc_solve_result(mpc_ctx *ctx, int count, void *ws, int rows, size_t ws_byte
     if (ctx->solve_ws != ws) return fail(ctx, MPC_ERR_INVALID_ARG, "mpc_solve_begin has not run on this context with this workspace");
     MPC_HIP(ctx, hipSetDevice(ctx->device));
     const mpck::SolveWorkspace W = mpck::carve_solve_workspace(ws, ctx->horizon, rows);
-    MPC_HIP(ctx, mpck::launch_solve_result(ctx->horizon, W, count, ctx->solve_slot, x, fun, nit, status, stats,
+    MPC_HIP(ctx, mpck::launch_solve_result(ctx->horizon, W, count, ctx->solve_round % 3, x, fun, nit, status, stats,
                                            static_cast<hipStream_t>(stream)));
     return MPC_OK;
 }

@@ -90,7 +90,8 @@ SolveWorkspace carve_solve_workspace(void *base, int H, int rows);
 size_t solve_workspace_bytes(int H, int rows);
 hipError_t launch_solve_begin(const mpc_params &P, const SolveWorkspace &W, int count, const double *x0, double acc, int maxiter,
                               hipStream_t stream);
-hipError_t launch_solve_body(int H, const SolveWorkspace &W, int bound, int old_slot, hipStream_t stream);
+// round r = 0, 1, ...: reads list buffer r % 2 and counter slot r % 3, fills buffer (r + 1) % 2 and slot (r + 1) % 3
+hipError_t launch_solve_body(int H, const SolveWorkspace &W, int bound, int round, hipStream_t stream);
 hipError_t launch_solve_result(int H, const SolveWorkspace &W, int count, int slot, double *x, double *fun, int32_t *nit,
                                int32_t *status, int32_t *stats, hipStream_t stream);
 hipError_t launch_solve_count(const SolveWorkspace &W, int slot, hipStream_t stream);

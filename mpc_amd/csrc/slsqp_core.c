@@ -631,13 +631,55 @@ void mpc_slsqp_bfgs_builtin(int m, int n, int la, double *l, double *g, double *
 #undef A
 }
 
+/* The loops of Kraft's body over the constraints (slsqp_body.inc): every chain of additions in the order of his
+ * text.  The device has its own forms of the same chains (kernels_slsqp.hip). */
+static void sl_fill(int n, double *x, double v)
+{
+    int i;
+    for (i = 0; i < n; ++i) x[i] = v;
+}
+/* t + sum_j max(-c(j), c(j) for j <= meq, else 0) */
+static double sl_sum_infeas(int m, int meq, const double *c, double t)
+{
+    int j;
+    for (j = 1; j <= m; ++j) {
+        const double h = (j <= meq) ? c[j - 1] : 0.0;
+        t = t + MAX(-c[j - 1], h);
+    }
+    return t;
+}
+/* t + sum_j mu(j) max(-c(j), c(j) for j <= meq, else 0) */
+static double sl_sum_mu_infeas(int m, int meq, const double *mu, const double *c, double t)
+{
+    int j;
+    for (j = 1; j <= m; ++j) {
+        const double h = (j <= meq) ? c[j - 1] : 0.0;
+        t = t + mu[j - 1] * MAX(-c[j - 1], h);
+    }
+    return t;
+}
+/* t + sum_j |r(j)| |c(j)| */
+static double sl_sum_abs_prod(int m, const double *r, const double *c, double t)
+{
+    int j;
+    for (j = 1; j <= m; ++j) t = t + fabs(r[j - 1]) * fabs(c[j - 1]);
+    return t;
+}
+/* mu(j) = max(|r(j)|, (mu(j) + |r(j)|) / 2) */
+static void sl_mu_update(int m, const double *r, double *mu)
+{
+    int j;
+    for (j = 1; j <= m; ++j) {
+        const double h = fabs(r[j - 1]);
+        mu[j - 1] = MAX(h, (mu[j - 1] + h) / 2.0);
+    }
+}
+
 void mpc_slsqpb(int m, int meq, int la, int n, double *x, double *xl, double *xu, double f, double *c, double *g, double *a,
                    double *acc, int *iter, int *mode, double *r, double *l, double *x0, double *mu, double *s, double *u,
                    double *v, double *w, int *iw, slsqp_state *S)
 #define SLSQP_BODY_FULL 1
-#define SLSQP_BODY_UNROLL
 #include "slsqp_body.inc"
-#undef SLSQP_BODY_UNROLL
 #undef SLSQP_BODY_FULL
 
 /* One reverse-communication call; arguments as scipy.optimize._slsqp.slsqp.  a is column-major (la, n+1). */

@@ -76,6 +76,8 @@ class _ResidentLane:
         slot = self.batches & 1                   # the older of the two in flight
         self.events[slot].synchronize()
         self.bound = int(self.left[slot])
+        if self.bound < 0:
+            raise RuntimeError("mpc_solve_rounds met more requests than its `bound` sized the grids for: the solve is void")
         if self.bound == 0:
             self.running = False
 
