@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MPC_AMD_ABI_VERSION 8
+#define MPC_AMD_ABI_VERSION 9
 #define MPC_MAX_HORIZON 255
 
 typedef enum mpc_status {
@@ -165,11 +165,23 @@ int mpc_fk(mpc_ctx *ctx, int count, const double *q, double *pose, void *stream)
  * the joint range is tested directly.  Needs no parameters set. */
 int mpc_sincos_probe(mpc_ctx *ctx, int count, const double *x, double *sn, double *cs, void *stream);
 
+/* Test hook, no counterpart in the reference: the ordered sum that the solver kernels run as one chain of FP64
+ * additions on a wavefront (mpc_amd/csrc/lsq_wave.hpp, ordered_sum_from; a computed jump into a block of 128 DPP
+ * instructions).  Case i: out[i] = ((t0[i] + terms[i][first[i]]) + terms[i][first[i] + 1]) + ... + terms[i][127],
+ * terms [count][128], first[i] in 0..128 (128: nothing is added).  Needs no parameters set. */
+int mpc_ordered_sum_probe(mpc_ctx *ctx, int count, const double *terms, const double *t0, const int32_t *first,
+                          double *out, void *stream);
+
 /* Batched platform predictor: replaces URMPC._predict_base_dynamic (MPC:606-651).
  * base [N][12] = [position, orientation, linear_velocity, angular_velocity] (base_observer.py:55-62),
  * dyn_host[6] = {mass, I_z, k_v, k_omega, tau_linear, tau_angular} (HOST pointer) -> base_traj [N][H][12]. */
 int mpc_predict_base_dynamic(mpc_ctx *ctx, int count, const double *base, const double *dyn_host,
                              double *base_traj, void *stream);
+/* The same with the commanded velocities of the actuator-lag model, the optional 'v_cmd' / 'omega_cmd' keys of the
+ * platform state (MPC:624-625): cmd [N][2] = [v_cmd, omega_cmd] per row, or NULL (then every row's commands are its
+ * current v and omega, i.e. mpc_predict_base_dynamic). */
+int mpc_predict_base_dynamic_cmd(mpc_ctx *ctx, int count, const double *base, const double *cmd, const double *dyn_host,
+                                 double *base_traj, void *stream);
 
 /* Everything URMPC.compute_control assembles before it calls minimize (MPC:104-185), for N controllers
  * in one launch, device to device:

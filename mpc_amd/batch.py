@@ -316,15 +316,28 @@ class MpcContext:
         _ffi.check(self._ctx, self._lib.mpc_sincos_probe(self._ctx, N, xp, sn.data_ptr(), cs.data_ptr(), self._stream()))
         return sn, cs
 
-    def predict_base_dynamic(self, base: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """Batched ``_predict_base_dynamic`` (ur_mpc.py:606-651): base [N,12] -> [N,H,12]."""
+    def ordered_sum_probe(self, terms: torch.Tensor, t0: torch.Tensor, first: torch.Tensor) -> torch.Tensor:
+        """The solver kernels' ordered wavefront sum on terms [N,128] (test hook, include/mpc_amd.h: mpc_ordered_sum_probe)."""
+        N = int(terms.shape[0])
+        tp = self._chk(terms, (N, 128), "terms")
+        zp = self._chk(t0, (N,), "t0")
+        fp = self._chk(first, (N,), "first", dtype=torch.int32)
+        out = self._new(N)
+        _ffi.check(self._ctx, self._lib.mpc_ordered_sum_probe(self._ctx, N, tp, zp, fp, out.data_ptr(), self._stream()))
+        return out
+
+    def predict_base_dynamic(self, base: torch.Tensor, out: Optional[torch.Tensor] = None,
+                             cmd: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Batched ``_predict_base_dynamic`` (ur_mpc.py:606-651): base [N,12] -> [N,H,12]; ``cmd`` [N,2] = the optional
+        commanded [v_cmd, omega_cmd] of the platform state (ur_mpc.py:624-625; default: the current v and omega)."""
         N = int(base.shape[0])
         bp = self._chk(base, (N, 12), "base")
+        cp = self._chk(cmd, (N, 2), "cmd", optional=True)
         if out is None:
             out = self._new(N, self.H, 12)
         else:
             self._chk(out, (N, self.H, 12), "base_traj")
         dyn = self.params.base_dyn_array()
-        _ffi.check(self._ctx, self._lib.mpc_predict_base_dynamic(
-            self._ctx, N, bp, dyn.ctypes.data_as(C.POINTER(C.c_double)), out.data_ptr(), self._stream()))
+        _ffi.check(self._ctx, self._lib.mpc_predict_base_dynamic_cmd(
+            self._ctx, N, bp, cp, dyn.ctypes.data_as(C.POINTER(C.c_double)), out.data_ptr(), self._stream()))
         return out

@@ -54,12 +54,13 @@ __global__ void fk_kernel(const mpc_params P, int N, const double *__restrict__ 
 
 struct BaseDyn { double mass, Iz, k_v, k_omega, tau_l, tau_a; };
 
-// MPC:606-651; v_cmd / omega_cmd default to the current v / omega (MPC:624-625)
-__device__ __forceinline__ void predict_base_dynamic_row(int H, double dt, const BaseDyn &D, const double *b, double *out)
+// MPC:606-651; v_cmd / omega_cmd (cmd[0], cmd[1]) default to the current v / omega (MPC:624-625)
+__device__ __forceinline__ void predict_base_dynamic_row(int H, double dt, const BaseDyn &D, const double *b, double *out,
+                                                         const double *cmd = nullptr)
 {
     double px = b[0], py = b[1], pz = b[2];
     double yaw = b[5], v = b[6], w = b[11];
-    const double v_cmd = v, w_cmd = w;
+    const double v_cmd = cmd ? cmd[0] : v, w_cmd = cmd ? cmd[1] : w;
     for (int k = 0; k < H; ++k) {
         const double force = (D.mass / D.tau_l) * (v_cmd - v);
         const double acc = (force - D.k_v * v) / D.mass;
@@ -81,11 +82,12 @@ __device__ __forceinline__ void predict_base_dynamic_row(int H, double dt, const
 }
 
 __global__ void predict_base_dynamic_kernel(int N, int H, double dt, const BaseDyn D,
-                                            const double *__restrict__ base, double *__restrict__ out)
+                                            const double *__restrict__ base, const double *__restrict__ cmd,
+                                            double *__restrict__ out)
 {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= N) return;
-    predict_base_dynamic_row(H, dt, D, base + (size_t)s * 12, out + (size_t)s * H * 12);
+    predict_base_dynamic_row(H, dt, D, base + (size_t)s * 12, out + (size_t)s * H * 12, cmd ? cmd + (size_t)s * 2 : nullptr);
 }
 
 // R(psi) v of MPC:714-720
@@ -228,11 +230,11 @@ hipError_t launch_fk(const mpc_params &P, int N, const double *q, double *pose, 
     return hipGetLastError();
 }
 
-hipError_t launch_predict_base_dynamic(int N, int H, double dt, const double *base, const double (&dyn)[6],
+hipError_t launch_predict_base_dynamic(int N, int H, double dt, const double *base, const double *cmd, const double (&dyn)[6],
                                        double *out, hipStream_t stream)
 {
     BaseDyn D{dyn[0], dyn[1], dyn[2], dyn[3], dyn[4], dyn[5]};
-    hipLaunchKernelGGL(predict_base_dynamic_kernel, dim3((N + 63) / 64), dim3(64), 0, stream, N, H, dt, D, base,
+    hipLaunchKernelGGL(predict_base_dynamic_kernel, dim3((N + 63) / 64), dim3(64), 0, stream, N, H, dt, D, base, cmd,
                        out);
     return hipGetLastError();
 }

@@ -400,6 +400,33 @@ hipError_t launch_solve_result(int H, const SolveWorkspace &W, int count, int sl
     return hipGetLastError();
 }
 
+namespace {
+// test hook: one wavefront per case, slot s = 16 r + c of the case in register r of the lanes with lane % 16 == c
+__global__ __launch_bounds__(64) void ordered_sum_probe_kernel(int count, const double *__restrict__ terms,
+                                                               const double *__restrict__ t0, const int32_t *__restrict__ first,
+                                                               double *__restrict__ out)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    const int i = (int)blockIdx.x, c = (int)(threadIdx.x & 15u);
+    if (i >= count) return;
+    double P[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) P[r] = terms[(size_t)i * 128 + 16 * r + c];
+    int f = first[i];
+    f = f < 0 ? 0 : (f > 128 ? 128 : f);
+    const double t = lsqwave::ordered_sum_from(t0[i], P, __builtin_amdgcn_readfirstlane(f));
+    if (threadIdx.x == 63) out[i] = t;           // every lane holds the sum: the last one says so
+#endif
+}
+}  // namespace
+
+hipError_t launch_ordered_sum_probe(int count, const double *terms, const double *t0, const int32_t *first, double *out,
+                                    hipStream_t stream)
+{
+    hipLaunchKernelGGL(ordered_sum_probe_kernel, dim3((unsigned)count), dim3(64), 0, stream, count, terms, t0, first, out);
+    return hipGetLastError();
+}
+
 hipError_t launch_solve_count(const SolveWorkspace &W, int slot, hipStream_t stream)
 {
     hipLaunchKernelGGL(solve_count_kernel, dim3(1), dim3(1), 0, stream, W.counters + 8 * slot, W.counters + kOverflow);

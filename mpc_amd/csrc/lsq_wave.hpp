@@ -94,6 +94,9 @@ __device__ __forceinline__ bool all_clean(const Flags &fl) { return __builtin_am
 // One instruction per term: v_fmac_f64 with its first factor taken from lane c of the row (DPP row_newbcast) and the
 // second 1.0, i.e. t = p * 1.0 + t.  The product is exact, so the one rounding is the addition's: the bits of t + p.
 // The 128 instructions are laid out back to back (8 bytes each) and entered at the first term by a computed jump.
+// The jump's arithmetic relies on two encodings - 12 bytes of scalar instructions between the address s_getpc returns
+// and the first term, 8 bytes per term - and the assembler checks both where the block is emitted (.if / .error on
+// the label differences); tests/test_gpu_solve.py::test_ordered_sum_enters_the_chain_at_every_term drives every entry.
 #define LSQW_T(r, c) "v_fmac_f64_dpp %[t], %[p" #r "], %[one] row_newbcast:" #c " row_mask:0xf bank_mask:0xf\n\t"
 #define LSQW_R(r)                                                                                                  \
     LSQW_T(r, 0) LSQW_T(r, 1) LSQW_T(r, 2) LSQW_T(r, 3) LSQW_T(r, 4) LSQW_T(r, 5) LSQW_T(r, 6) LSQW_T(r, 7)          \
@@ -105,11 +108,20 @@ __device__ __forceinline__ double ordered_sum_from(double t, const double (&p)[8
     // plus 8 bytes per skipped term further on; first == 128 skips them all
     const int off = 12 + 8 * first;
     asm volatile("s_nop 1\n\t"                       // a VALU result (p) may not be read through DPP in the next two slots
-                 "s_getpc_b64 s[38:39]\n\t"
+                 "s_getpc_b64 s[38:39]\n"
+                 ".Llsqw_pc%=:\n\t"
                  "s_add_u32 s38, s38, %[off]\n\t"
                  "s_addc_u32 s39, s39, 0\n\t"
-                 "s_setpc_b64 s[38:39]\n\t"
+                 "s_setpc_b64 s[38:39]\n"
+                 ".Llsqw_first%=:\n\t"
                  LSQW_R(0) LSQW_R(1) LSQW_R(2) LSQW_R(3) LSQW_R(4) LSQW_R(5) LSQW_R(6) LSQW_R(7)
+                 "\n.Llsqw_end%=:\n\t"
+                 ".if (.Llsqw_first%= - .Llsqw_pc%=) != 12\n\t"
+                 ".error \"ordered_sum_from: the scalar instructions of the computed jump are not 12 bytes\"\n\t"
+                 ".endif\n\t"
+                 ".if (.Llsqw_end%= - .Llsqw_first%=) != 1024\n\t"
+                 ".error \"ordered_sum_from: a term is not one 8-byte instruction\"\n\t"
+                 ".endif\n\t"
                  : [t] "+v"(t)
                  : [p0] "v"(p[0]), [p1] "v"(p[1]), [p2] "v"(p[2]), [p3] "v"(p[3]), [p4] "v"(p[4]), [p5] "v"(p[5]),
                    [p6] "v"(p[6]), [p7] "v"(p[7]), [one] "v"(one), [off] "s"(off)

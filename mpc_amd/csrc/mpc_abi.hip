@@ -368,8 +368,26 @@ int mpc_sincos_probe(mpc_ctx *ctx, int count, const double *x, double *sn, doubl
     return MPC_OK;
 }
 
+int mpc_ordered_sum_probe(mpc_ctx *ctx, int count, const double *terms, const double *t0, const int32_t *first, double *out,
+                          void *stream)
+{
+    if (!ctx) return MPC_ERR_INVALID_ARG;
+    if (count < 0 || (count > 0 && (!terms || !t0 || !first || !out)))
+        return fail(ctx, MPC_ERR_INVALID_ARG, "bad count / NULL terms, t0, first or out");
+    if (count == 0) return MPC_OK;
+    MPC_HIP(ctx, hipSetDevice(ctx->device));
+    MPC_HIP(ctx, mpck::launch_ordered_sum_probe(count, terms, t0, first, out, static_cast<hipStream_t>(stream)));
+    return MPC_OK;
+}
+
 int mpc_predict_base_dynamic(mpc_ctx *ctx, int count, const double *base, const double *dyn_host,
                              double *base_traj, void *stream)
+{
+    return mpc_predict_base_dynamic_cmd(ctx, count, base, nullptr, dyn_host, base_traj, stream);
+}
+
+int mpc_predict_base_dynamic_cmd(mpc_ctx *ctx, int count, const double *base, const double *cmd, const double *dyn_host,
+                                 double *base_traj, void *stream)
 {
     int rc = check_ready(ctx);
     if (rc) return rc;
@@ -382,7 +400,7 @@ int mpc_predict_base_dynamic(mpc_ctx *ctx, int count, const double *base, const 
     double dyn[6];
     std::memcpy(dyn, dyn_host, sizeof(dyn));
     MPC_HIP(ctx, hipSetDevice(ctx->device));
-    MPC_HIP(ctx, mpck::launch_predict_base_dynamic(count, ctx->horizon, ctx->params.dt_con, base, dyn, base_traj,
+    MPC_HIP(ctx, mpck::launch_predict_base_dynamic(count, ctx->horizon, ctx->params.dt_con, base, cmd, dyn, base_traj,
                                                    static_cast<hipStream_t>(stream)));
     return MPC_OK;
 }

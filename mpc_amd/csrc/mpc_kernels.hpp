@@ -45,7 +45,7 @@ size_t prefix_workspace_doubles_per_scenario(const mpc_params &P);
 
 hipError_t launch_jacobian(const mpc_params &P, int N, const double *q, double *J, hipStream_t stream);
 hipError_t launch_fk(const mpc_params &P, int N, const double *q, double *pose, hipStream_t stream);
-hipError_t launch_predict_base_dynamic(int N, int H, double dt, const double *base, const double (&dyn)[6],
+hipError_t launch_predict_base_dynamic(int N, int H, double dt, const double *base, const double *cmd, const double (&dyn)[6],
                                        double *out, hipStream_t stream);
 
 // MPC:104-185 for N controllers: early-exit flag, state0, platform prediction, Jc, DLS start, start point
@@ -95,6 +95,8 @@ hipError_t launch_solve_body(int H, const SolveWorkspace &W, int bound, int roun
 hipError_t launch_solve_result(int H, const SolveWorkspace &W, int count, int slot, double *x, double *fun, int32_t *nit,
                                int32_t *status, int32_t *stats, hipStream_t stream);
 hipError_t launch_solve_count(const SolveWorkspace &W, int slot, hipStream_t stream);
+hipError_t launch_ordered_sum_probe(int count, const double *terms, const double *t0, const int32_t *first, double *out,
+                                    hipStream_t stream);
 // One request list of a device-resident solve: evaluate rows list[0 .. *count) of the per-problem arrays in place
 // (x from XE, outputs to the problem's own rows).  `bound` >= *count sizes the grid; surplus workgroups exit.
 struct RowList {

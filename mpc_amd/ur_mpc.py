@@ -31,6 +31,15 @@ def _pack_base(b: Dict) -> np.ndarray:
                            np.asarray(b["linear_velocity"], float)[:3], np.asarray(b["angular_velocity"], float)])
 
 
+def _base_commands(base_state: Dict) -> Optional[np.ndarray]:
+    """[v_cmd, omega_cmd] of a platform state that carries either key, each defaulting to the current body-x speed /
+    yaw rate like ``dict.get`` in ur_mpc.py:624-625; None when the state has neither."""
+    if "v_cmd" not in base_state and "omega_cmd" not in base_state:
+        return None
+    return np.array([float(base_state.get("v_cmd", base_state["linear_velocity"][0])),
+                     float(base_state.get("omega_cmd", base_state["angular_velocity"][2]))])
+
+
 def _unpack_base_traj(arr: np.ndarray) -> List[Dict]:
     return [{"position": r[0:3].copy(), "orientation": r[3:6].copy(), "linear_velocity": r[6:9].copy(),
              "angular_velocity": r[9:12].copy()} for r in arr.reshape(-1, 12)]
@@ -162,7 +171,7 @@ class GpuURMPC:
         dev, n, m, H = ctx.device, p.n, p.m, p.horizon
         z = lambda *shape: torch.zeros(shape, dtype=torch.float64, device=dev)
         pin = lambda count: torch.zeros(count, dtype=torch.float64).pin_memory()
-        self._qb_h, self._qb_d = pin(18), z(18)                       # [q(6), platform state(12)]
+        self._qb_h, self._qb_d = pin(20), z(20)                       # [q(6), platform state(12), v_cmd, omega_cmd]
         self._jc_h = pin(36)
         self._in_h, self._in_d = pin(30), z(30)                       # [state0(18), target(6), previous_control(6)]
         self._x_h, self._x_d = pin(n), z(1, n)
@@ -297,14 +306,15 @@ class GpuURMPC:
 
     # ---- platform predictors ---------------------------------------------------------------------
     def _predict_base_dynamic(self, current_base_state: Dict, horizon: int) -> List[Dict]:
-        """ur_mpc.py:606-651 on the device.  Commanded velocities ('v_cmd'/'omega_cmd') are not part of
-        the odometry dict the server passes (base_observer.py:55-62); when present they are rejected."""
-        if "v_cmd" in current_base_state or "omega_cmd" in current_base_state:
-            raise ValueError("v_cmd/omega_cmd are not supported by the device predictor")
+        """ur_mpc.py:606-651 on the device, the optional commanded velocities 'v_cmd' / 'omega_cmd' of the
+        actuator-lag model included (ur_mpc.py:624-625; the odometry dict the server passes has neither,
+        base_observer.py:55-62)."""
         if horizon != self.horizon:
             raise ValueError("horizon is fixed per controller")
         b = torch.as_tensor(_pack_base(current_base_state).reshape(1, 12)).to(self._ctx.device)
-        return _unpack_base_traj(self._ctx.predict_base_dynamic(b)[0].cpu().numpy())
+        cmd = _base_commands(current_base_state)
+        cmd_d = None if cmd is None else torch.as_tensor(cmd.reshape(1, 2)).to(self._ctx.device)
+        return _unpack_base_traj(self._ctx.predict_base_dynamic(b, cmd=cmd_d)[0].cpu().numpy())
 
     def _predict_base_kinematic(self, current_base_state: Dict, horizon: int) -> List[Dict]:
         """ur_mpc.py:527-601 (host glue, stateful)."""
@@ -348,14 +358,17 @@ class GpuURMPC:
             ctx = self._ctx
             qb = self._qb_h.numpy()
             qb[0:6] = current_joint_state["position"]
+            cmd = None
             if self.use_dynamic_model:
-                if "v_cmd" in base_state or "omega_cmd" in base_state:
-                    raise ValueError("v_cmd/omega_cmd are not supported by the device predictor")
                 qb[6:18] = _pack_base(base_state)
+                cmd = _base_commands(base_state)                              # ur_mpc.py:624-625
+                if cmd is not None:
+                    qb[18:20] = cmd
             self._qb_d.copy_(self._qb_h, non_blocking=True)
             ctx.jacobian(self._qb_d[0:6].view(1, 6), out=self._jc_d)
             if self.use_dynamic_model:
-                ctx.predict_base_dynamic(self._qb_d[6:18].view(1, 12), out=self._bt_d)
+                ctx.predict_base_dynamic(self._qb_d[6:18].view(1, 12), out=self._bt_d,
+                                         cmd=None if cmd is None else self._qb_d[18:20].view(1, 2))
             else:
                 bt = np.stack([_pack_base(b) for b in self._predict_base_kinematic(base_state, self.horizon)])
                 self._bt_d.copy_(torch.from_numpy(bt).view(1, self.horizon, 12))

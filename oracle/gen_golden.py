@@ -289,6 +289,46 @@ def base_motion_cases():
                         dynamic=np.stack(dyn_out), kinematic=np.stack(kin_out))
 
 
+def base_cmd_cases():
+    """The dynamic predictor of the reference with the optional commanded velocities 'v_cmd' / 'omega_cmd' in the
+    platform state (ur_mpc.py:624-625), and compute_control ticks (H=3, two each) fed such states."""
+    rng = np.random.default_rng(78)
+    H = 3
+    mp = MpcParams.reference_yaml_defaults(horizon=H)
+    kin = OracleKinematics(COracle(ref_params_from(mp)))
+    hs = make_scenarios(mp, kin, 4, motion="linear", cfg_id=260, goal_jitter=0.0)
+    cmds = np.array([[0.25, 0.05], [-0.1, np.nan], [np.nan, -0.08], [0.0, 0.0]])    # NaN: that key is absent
+    pack = lambda tr: np.array([np.concatenate([e["position"], e["orientation"], e["linear_velocity"],
+                                                 e["angular_velocity"]]) for e in tr])
+    trajs, controls, sols = [], [], []
+    for i in range(4):
+        b = hs.base[i].copy()
+        b[11] = rng.uniform(-0.05, 0.05)                      # some yaw rate as well
+        hs.base[i] = b
+        bs = {"position": b[0:3].copy(), "orientation": b[3:6].copy(), "linear_velocity": b[6:9].copy(),
+              "angular_velocity": b[9:12].copy()}
+        if not np.isnan(cmds[i, 0]):
+            bs["v_cmd"] = float(cmds[i, 0])
+        if not np.isnan(cmds[i, 1]):
+            bs["omega_cmd"] = float(cmds[i, 1])
+        ref = _ref_for(H)
+        trajs.append(pack(ref.predict_base_motion(bs, H)))
+        js = {"position": hs.q0[i].copy(), "velocity": np.zeros(6)}
+        ee = {"position": hs.state0[i, 12:15].copy(), "orientation": hs.state0[i, 15:18].copy()}
+        tg = {"position": hs.target[i, :3].copy(), "orientation": hs.target[i, 3:].copy()}
+        cu, so = [], []
+        for tick in range(2):
+            with contextlib.redirect_stdout(io.StringIO()):
+                u = ref.compute_control(js, ee, tg, bs)
+            cu.append(np.array(u))
+            so.append(np.array(ref.previous_solution) if ref.previous_solution is not None else np.full(6 * H, np.nan))
+        controls.append(np.stack(cu))
+        sols.append(np.stack(so))
+    np.savez_compressed(os.path.join(OUT, "base_motion_cmd.npz"), H=np.int64(H), base=hs.base, cmd=cmds, q0=hs.q0,
+                        ee=hs.state0[:, 12:18], target=hs.target, dynamic=np.stack(trajs), control=np.stack(controls),
+                        solution=np.stack(sols))
+
+
 def main():
     if not ref_shim.reference_available():
         sys.exit("reference tree not present: fixtures can only be generated where /root/reference exists")
@@ -299,7 +339,11 @@ def main():
     if "--h100" in sys.argv:         # only the configs[3] angular eval fixture
         h100_angular_cases()
         return
+    if "--base-cmd" in sys.argv:     # only the commanded-velocity fixture
+        base_cmd_cases()
+        return
     base_motion_cases()
+    base_cmd_cases()
     save_eval(eval_cases())
     save_solve(solve_cases())
     h20_cases()

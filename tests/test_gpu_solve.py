@@ -5,6 +5,7 @@ import numpy as np
 import pytest
 import torch
 
+from mpc_amd.batch import MpcContext
 from mpc_amd.params import MpcParams
 from mpc_amd.ur_mpc import GpuURMPC
 
@@ -52,6 +53,40 @@ def test_compute_control_matches_reference(golden_dir, H):
         js, ee, tg, bs = _dicts(g, i)
         for tick in range(g["control"].shape[1]):   # tick 1 exercises warm start, damping, EMA
             u = mpc.compute_control(js, ee, tg, bs)
+            np.testing.assert_allclose(mpc.previous_solution, g["solution"][i, tick], rtol=0, atol=SOL_ATOL)
+            np.testing.assert_allclose(u, g["control"][i, tick], rtol=0, atol=SOL_ATOL)
+
+
+@pytest.mark.parametrize("solver", ["scipy", "resident"])
+def test_commanded_velocities_reach_the_platform_model(golden_dir, solver):
+    """A platform state with 'v_cmd' / 'omega_cmd' (ur_mpc.py:624-625) through the device predictor and through whole
+    compute_control ticks, against what the real reference made of the same states (base_motion_cmd.npz)."""
+    path = os.path.join(golden_dir, "base_motion_cmd.npz")
+    if not os.path.exists(path):
+        pytest.fail("base_motion_cmd.npz missing: python -m oracle.gen_golden --base-cmd (where /root/reference exists)")
+    if not torch.cuda.is_available():
+        pytest.fail("no GPU visible")
+    g = np.load(path, allow_pickle=False)
+    H = int(g["H"])
+    for i in range(g["base"].shape[0]):
+        b = g["base"][i]
+        bs = {"position": b[0:3].copy(), "orientation": b[3:6].copy(), "linear_velocity": b[6:9].copy(),
+              "angular_velocity": b[9:12].copy()}
+        if not np.isnan(g["cmd"][i, 0]):
+            bs["v_cmd"] = float(g["cmd"][i, 0])
+        if not np.isnan(g["cmd"][i, 1]):
+            bs["omega_cmd"] = float(g["cmd"][i, 1])
+        mpc = GpuURMPC(MpcParams.reference_yaml_defaults(horizon=H), solver=solver)
+        got = mpc.predict_base_motion(bs, H)
+        arr = np.array([np.concatenate([e["position"], e["orientation"], e["linear_velocity"], e["angular_velocity"]])
+                        for e in got])
+        np.testing.assert_allclose(arr, g["dynamic"][i], rtol=1e-14, atol=1e-15)     # the device's sin/cos vs numpy's
+        js = {"position": g["q0"][i].copy(), "velocity": np.zeros(6)}
+        ee = {"position": g["ee"][i, :3].copy(), "orientation": g["ee"][i, 3:].copy()}
+        tg = {"position": g["target"][i, :3].copy(), "orientation": g["target"][i, 3:].copy()}
+        for tick in range(2):
+            u = mpc.compute_control(js, ee, tg, bs)
+            assert np.abs(u).max() > 1e-3                                            # not the zero command of a swallowed error
             np.testing.assert_allclose(mpc.previous_solution, g["solution"][i, tick], rtol=0, atol=SOL_ATOL)
             np.testing.assert_allclose(u, g["control"][i, tick], rtol=0, atol=SOL_ATOL)
 
@@ -704,3 +739,31 @@ def test_prepare_tick_rejects_an_in_place_warm_start_shift():
                                    dyn.ctypes.data_as(C.POINTER(C.c_double)), prev.data_ptr(), has.data_ptr(), st.data_ptr(),
                                    bt.data_ptr(), jc.data_ptr(), ui.data_ptr(), prev.data_ptr(), act.data_ptr(), ctx._stream())
     assert rc == -1 and b"overlap" in ctx._lib.mpc_last_error(ctx._ctx)
+
+
+def test_ordered_sum_enters_the_chain_at_every_term():
+    """lsq_wave.hpp's ordered_sum_from (a computed jump into 128 back-to-back DPP instructions; every recurrence of the
+    QP kernel and every sum of the body kernel runs through it) against the plain loop, bit for bit, for every entry
+    point first = 0..128, with terms whose sum depends on the order of the additions."""
+    if not torch.cuda.is_available():
+        pytest.fail("no GPU visible")
+    ctx = MpcContext(MpcParams.reference_yaml_defaults(horizon=1), 1, 0)
+    rng = np.random.default_rng(7)
+    reps = 3
+    first = np.tile(np.arange(129, dtype=np.int32), reps)
+    N = len(first)
+    terms = rng.standard_normal((N, 128)) * np.exp(rng.uniform(-30, 30, (N, 128)))     # magnitudes over 26 decades
+    t0 = rng.standard_normal(N)
+    t0[:129] = 0.0
+    want = t0.copy()
+    for i in range(N):
+        t = want[i]
+        for j in range(first[i], 128):
+            t = t + terms[i, j]
+        want[i] = t
+    dev = lambda a, dt=torch.float64: torch.as_tensor(a, dtype=dt).to(ctx.device)
+    got = ctx.ordered_sum_probe(dev(terms), dev(t0), dev(first, torch.int32)).cpu().numpy()
+    np.testing.assert_array_equal(got, want)
+    # the order matters for these terms: a reversed chain gives other bits somewhere
+    rev = np.array([np.sum(terms[i, first[i]:][::-1]) for i in range(200)])
+    assert (rev != want[:200]).any()

@@ -90,6 +90,39 @@ def test_base_motion_golden(golden_dir):
         np.testing.assert_array_equal(base_traj_to_array(npref.predict_base_motion(bs, H)), g["kinematic"][t])
 
 
+def _cmd_state(g, i):
+    b = g["base"][i]
+    bs = {"position": b[0:3].copy(), "orientation": b[3:6].copy(), "linear_velocity": b[6:9].copy(),
+          "angular_velocity": b[9:12].copy()}
+    if not np.isnan(g["cmd"][i, 0]):
+        bs["v_cmd"] = float(g["cmd"][i, 0])
+    if not np.isnan(g["cmd"][i, 1]):
+        bs["omega_cmd"] = float(g["cmd"][i, 1])
+    return bs
+
+
+def test_base_motion_with_commanded_velocities_golden(golden_dir):
+    """ur_mpc.py:624-625: the optional 'v_cmd' / 'omega_cmd' of the platform state drive the actuator-lag model; the
+    reference's own trajectories and two compute_control ticks fed such states (oracle/gen_golden.py --base-cmd)."""
+    g = _golden(golden_dir, "base_motion_cmd.npz")
+    H = int(g["H"])
+    assert np.isnan(g["cmd"]).sum() == 2            # one case without v_cmd, one without omega_cmd
+    for i in range(g["base"].shape[0]):
+        ref = NumpyRefMPC(RefParams(horizon=H))
+        bs = _cmd_state(g, i)
+        np.testing.assert_array_equal(base_traj_to_array(ref.predict_base_motion(bs, H)), g["dynamic"][i])
+        plain = {k: v for k, v in bs.items() if k not in ("v_cmd", "omega_cmd")}
+        if i < 3:
+            assert not np.array_equal(base_traj_to_array(ref.predict_base_motion(plain, H)), g["dynamic"][i])
+        js = {"position": g["q0"][i].copy(), "velocity": np.zeros(6)}
+        ee = {"position": g["ee"][i, :3].copy(), "orientation": g["ee"][i, 3:].copy()}
+        tg = {"position": g["target"][i, :3].copy(), "orientation": g["target"][i, 3:].copy()}
+        for tick in range(2):
+            u = ref.compute_control(js, ee, tg, bs)
+            np.testing.assert_array_equal(u, g["control"][i, tick])
+            np.testing.assert_array_equal(ref.previous_solution, g["solution"][i, tick])
+
+
 def test_jacobian_is_derivative_of_fk():
     """The Jacobian provider (this repo's own, unpinned vs MoveIt) is at least self-consistent."""
     rng = np.random.default_rng(5)
