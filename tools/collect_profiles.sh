@@ -3,12 +3,12 @@
 set -e
 src=$1; dst=$2
 mkdir -p $dst
-cp $src/bench_line*.json $src/pmc_summary_*.txt $src/qp_solve_4096.txt $src/solve_cfg3_65536_resident.txt $dst/
+cp $src/bench_line*.json $src/bench_sweep*.json $src/pmc_summary_*.txt $src/qp_solve_4096.txt $src/solve_cfg3_65536_resident.txt $dst/
 for k in kt_h20:kernel_stats_bench_only_main kt_h100:kernel_stats_bench_only_main_H100_N16384 kt_qp:kernel_stats_qp_solve_4096 kt_solve:kernel_stats_solve_cfg3_65536_resident; do
   f=$(find $src/${k%%:*} -name "*kernel_stats.csv" -printf "%T@ %p\n" | sort -n | tail -1 | cut -d" " -f2-)    # the newest: merges pile up
   [ -n "$f" ] && cp $f $dst/${k##*:}.csv
 done
-python3 tools/profiles_json.py $dst \
+python3 tools/profiles_json.py $dst --qp $dst/pmc_summary_qp_kernel_4096.txt:20:4096:$dst/kernel_stats_solve_cfg3_65536_resident.csv \
   $dst/pmc_summary_prefix_H20_N65536.txt:jac:20:65536 \
   $dst/pmc_summary_prefix_H20_N65536_gradient_only.txt:nojac:20:65536 \
   $dst/pmc_summary_prefix_H20_N65536_structured.txt:nz:20:65536 \

@@ -1,7 +1,10 @@
 """Turns the text summaries of tools/pmc.sh into the two small JSON files bench.py reads:
    traffic*.json       HBM bytes per launch = WRITE_SIZE + 2 x FETCH_SIZE (KiB; the gfx950 correction of MI355X_MICROARCH.md)
    executed_fp64.json  FP64 operations the kernel EXECUTED per launch = 64 x (ADD + MUL + 2 FMA + TRANS) wavefront instructions
-usage: profiles_json.py <profiles/rNN> summary.txt:variant:H:N[:kernel-substring[:dispatches per launch]] ..."""
+   qp_roofline.json    (--qp summary.txt:H:QPs per launch:kernel_stats.csv) the same two figures per QP step of the solver's
+                       dominant kernel, its lane occupancy, and its share of the GPU time of a full-size solve
+usage: profiles_json.py <profiles/rNN> [--qp pmc_summary_qp.txt:H:K:kernel_stats_solve.csv]
+                        summary.txt:variant:H:N[:kernel-substring[:dispatches per launch]] ..."""
 import json, os, re, sys
 
 
@@ -17,10 +20,46 @@ def parse(path):
     return out
 
 
+def qp_roofline(dst, spec):
+    """pmc_qp.sh's flat summary (one kernel) + the kernel trace of a full-size resident solve -> qp_roofline.json"""
+    import csv
+    path, H, K, stats = spec.split(":")
+    c = {}
+    for line in open(path):
+        m = re.match(r"(\S+)\s+n=(\d+) mean=(\S+)", line)
+        if m:
+            c[m.group(1)] = float(m.group(3))
+    K = float(K)
+    flops = 64.0 * (c["SQ_INSTS_VALU_ADD_F64"] + c["SQ_INSTS_VALU_MUL_F64"] + 2.0 * c["SQ_INSTS_VALU_FMA_F64"] + c["SQ_INSTS_VALU_TRANS_F64"])
+    rows = list(csv.DictReader(open(stats)))
+    total = sum(float(r["TotalDurationNs"]) for r in rows)
+    qp = [r for r in rows if "qp_step_kernel" in r["Name"]]
+    occ = (c["SQ_THREAD_CYCLES_VALU"] / (64.0 * c["SQ_ACTIVE_INST_VALU"])
+           if "SQ_THREAD_CYCLES_VALU" in c and c.get("SQ_ACTIVE_INST_VALU") else None)
+    out = {"kernel": "qp_step_kernel<true, true>", "horizon": int(H), "qps_per_counter_launch": K,
+           "wave_instructions_per_launch": {k[14:]: c[k] for k in c if k.startswith("SQ_INSTS_VALU_") and k.endswith("F64")},
+           "executed_flops_per_qp": flops / K, "lane_occupancy": occ,
+           "FETCH_SIZE_KiB": c["FETCH_SIZE"], "WRITE_SIZE_KiB": c["WRITE_SIZE"], "fetch_correction": 2.0,
+           "traffic_bytes_per_qp": 1024.0 * (c["WRITE_SIZE"] + 2.0 * c["FETCH_SIZE"]) / K,
+           "l2_hit_rate": c["TCC_HIT_sum"] / (c["TCC_HIT_sum"] + c["TCC_MISS_sum"]) if "TCC_HIT_sum" in c else None,
+           "wait_share_of_wave_cycles": c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"] if "SQ_WAIT_ANY" in c else None,
+           "share_of_gpu_time": sum(float(r["TotalDurationNs"]) for r in qp) / total,
+           "share_source": os.path.basename(stats), "source": os.path.basename(path),
+           "note": "counters over K recorded QP subproblems of real solves (tools/qp_time.py); the share is the kernel's part of "
+                   "the summed kernel time of one 65,536-scenario resident solve (rocprofv3 --kernel-trace --stats)"}
+    json.dump(out, open(os.path.join(dst, "qp_roofline.json"), "w"), indent=1)
+    print(f"qp_roofline.json: {out['executed_flops_per_qp'] / 1e6:.2f} Mflop and {out['traffic_bytes_per_qp'] / 1e6:.2f} MB per QP, "
+          f"share {out['share_of_gpu_time']:.3f}")
+
+
 def main():
     dst = sys.argv[1]
     fp64, traffic = [], []
-    for spec in sys.argv[2:]:
+    specs = sys.argv[2:]
+    if specs and specs[0] == "--qp":
+        qp_roofline(dst, specs[1])
+        specs = specs[2:]
+    for spec in specs:
         parts = spec.split(":")
         path, variant, H, N = parts[0], parts[1], int(parts[2]), int(parts[3])
         want = parts[4] if len(parts) > 4 else "prefix_kernel"

@@ -10,6 +10,8 @@ export TMPDIR=/tmp
 cd $R
 timeout -k 10 400 python3 -u bench.py > $out/bench_line.json
 echo "bench done"
+timeout -k 10 300 python3 -u bench.py --workload sweep --motion angular --no-cpu-baseline > $out/bench_sweep_angular_131072.json
+echo "bench (configs[4] shard) done"
 cd /tmp
 timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt_h20 -- python3 $R/bench.py --only-main > $out/bench_line_only_main.json 2> $out/kt_h20.log
 echo "kernel trace H=20 done"
