@@ -177,6 +177,7 @@ SPMD_HD int nnls(const Team &T, const Work &W, int mrow, int ncol, int mg, doubl
     double *b = W.bb, *x = W.xn, *w = W.wd, *z = W.zz;
     int *index = W.idx;
     int iter = 0, iz1 = 1, nsetp = 0, npp1 = 1, mode = 1;
+    bool dual_ready = false;           // w already holds the duals of the columns in Z (made by the Householder pass)
     const int itmax = 3 * ncol, iz2 = ncol, m = mrow;
     if (mrow <= 0 || ncol <= 0) return 2;
     PAR_FOR(T, i, 0, ncol) { index[i] = i + 1; x[i] = 0.0; }
@@ -185,8 +186,9 @@ SPMD_HD int nnls(const Team &T, const Work &W, int mrow, int ncol, int mg, doubl
         // ---- L110: dual variables of the columns still in Z
         if (iz1 > iz2 || nsetp >= m) break;
         // two columns per thread at a time: twice as many loads in flight from the matrix (global memory), each
-        // column's sum still in the order of its rows
-        for (int t = iz1 - 1 + T.tid(); t < iz2; t += 2 * T.size()) {
+        // column's sum still in the order of its rows.  (Not after a Householder pass that left the set as it is: that
+        // pass has formed these very sums from the entries it was writing, see below.)
+        for (int t = iz1 - 1 + T.tid(); t < iz2 && !dual_ready; t += 2 * T.size()) {
             const int t2 = t + T.size();
             const bool two = t2 < iz2;
             const int j = index[t], j2 = two ? index[t2] : j;
@@ -214,6 +216,7 @@ SPMD_HD int nnls(const Team &T, const Work &W, int mrow, int ncol, int mg, doubl
             w[j - 1] = s;
             if (two) w[j2 - 1] = s2;
         }
+        dual_ready = false;
         T.sync();
         QP_MARK(T, 16);   // NNLS: dual pass
         int accepted = 0, j = 0, iz = 0;
@@ -258,7 +261,99 @@ SPMD_HD int nnls(const Team &T, const Work &W, int mrow, int ncol, int mg, doubl
             //      new pivot entry is written back, and only when the column is accepted)
             PAR_FOR(T, r, 0, m) { W.piv[r] = AT(r + 1, j); z[r] = b[r]; }
             T.sync();
-            if (T.tid() == 0) {
+            bool tested = false;
+#if defined(__HIP_DEVICE_COMPILE__)
+            if constexpr (Team::kWave) {
+                if (m <= lsqwave::kMaxN) {
+                    // The same test on the team's first wavefront (lsq_wave.hpp): the two ordered sums over the column
+                    // run as chains of DPP additions (entry i of the column in slot i + 128 - m, so that every sum ends
+                    // at the last slot and is entered at its first term), the largest magnitude by an exchange inside
+                    // the rows of 16 lanes (a maximum does not depend on the order it is formed in; NaN entries lose
+                    // every comparison in both forms), the update of z by the lanes.  Scalars are computed by every
+                    // lane alike; lane 0 files them away.
+                    tested = true;
+                    if (T.tid() < 64) {
+                        const int lane = lsqwave::lane_here(), c16 = lane & 15, pad = lsqwave::kMaxN - m;
+                        double pcv[8], zv[8];
+                        SPMD_UNROLL
+                        for (int rr = 0; rr < 8; ++rr) {
+                            const int i = 16 * rr + c16 - pad;
+                            pcv[rr] = i >= 0 ? W.piv[i] : 0.0;
+                            zv[rr] = i >= 0 ? z[i] : 0.0;
+                        }
+                        const double p0 = W.piv[npp1 - 1], z0 = z[npp1 - 1];
+                        double cl = fabs(p0), upv = 0.0, pivot = p0, znew = z0;
+                        int ok = 1;
+                        if (npp1 + 1 <= m) {               // h12 does nothing when l1 > m
+                            SPMD_UNROLL
+                            for (int rr = 0; rr < 8; ++rr) {
+                                const int i = 16 * rr + c16 - pad;
+                                const double sm = fabs(pcv[rr]);
+                                if (i >= npp1) cl = sm > cl ? sm : cl;
+                            }
+                            SPMD_UNROLL
+                            for (int off = 8; off > 0; off >>= 1) {
+                                const double o = __shfl_xor(cl, off, 16);
+                                cl = o > cl ? o : cl;
+                            }
+                            if (cl > 0.0) {
+                                const double clinv = 1.0 / cl;
+                                double sm = (p0 * clinv) * (p0 * clinv);
+                                double P[8];
+                                SPMD_UNROLL
+                                for (int rr = 0; rr < 8; ++rr) P[rr] = (pcv[rr] * clinv) * (pcv[rr] * clinv);
+                                sm = lsqwave::ordered_sum_from(sm, P, pad + npp1);
+                                cl = cl * sqrt(sm);
+                                if (p0 > 0.0) cl = -cl;
+                                upv = p0 - cl;
+                                pivot = cl;
+                            }
+                        }
+                        {
+                            const double unorm = nrm2(nsetp, W.piv, 1);      // the rows already in the triangle
+                            const double t = factor * fabs(pivot);
+                            volatile double d = unorm + t;
+                            if (d - unorm <= 0.0) ok = 0;
+                        }
+                        if (ok) {
+                            // h12 apply (mode 2) to z (= b) with pivot npp1, l1 = npp1 + 1
+                            if (npp1 + 1 <= m && fabs(pivot) > 0.0) {
+                                double bq = upv * pivot;
+                                if (bq < 0.0) {
+                                    bq = 1.0 / bq;
+                                    double sm = z0 * upv;
+                                    double P[8];
+                                    SPMD_UNROLL
+                                    for (int rr = 0; rr < 8; ++rr) P[rr] = zv[rr] * pcv[rr];
+                                    sm = lsqwave::ordered_sum_from(sm, P, pad + npp1);
+                                    if (sm != 0.0) {
+                                        sm = sm * bq;
+                                        znew = z0 + sm * upv;
+                                        if (lane < 16) {
+                                            SPMD_UNROLL
+                                            for (int rr = 0; rr < 8; ++rr) {
+                                                const int i = 16 * rr + c16 - pad;
+                                                if (i >= npp1) z[i] = zv[rr] + sm * pcv[rr];
+                                            }
+                                        }
+                                    }
+                                }
+                            }
+                            if (!(znew / pivot > 0.0)) ok = 0;
+                        }
+                        if (lane == 0) {
+                            W.piv[npp1 - 1] = pivot;
+                            z[npp1 - 1] = znew;
+                            if (ok) AT(npp1, j) = pivot;
+                            else w[j - 1] = 0.0;
+                            W.isc[1] = ok;
+                            W.sc[1] = upv;
+                        }
+                    }
+                }
+            }
+#endif
+            if (!tested && T.tid() == 0) {
                 double *pc = W.piv;                  // pc[r - 1] = a(r, j)
                 // h12 construct on rows npp1..m of column j
                 double cl = fabs(pc[npp1 - 1]), upv = 0.0;
@@ -320,37 +415,102 @@ SPMD_HD int nnls(const Team &T, const Work &W, int mrow, int ncol, int mg, doubl
         npp1 = npp1 + 1;
         T.sync();
         {
-            // h12 apply (pivot nsetp, l1 = npp1) to every column still in Z, one column per index
+            // h12 apply (pivot nsetp, l1 = npp1) to every column still in Z.  The same walk forms the column's dual for
+            // the next pass of the loop, w = sum over rows npp1..m of a(r, jj) b(r) in the order of the rows (b is final
+            // since step five; rows where b is zero are left out as in the dual pass): from the entries as they are
+            // read if the column stays as it is, from the new entries as they are written otherwise.
+            // Two columns per thread at a time (twice as many loads in flight: the walk waits for the matrix in global
+            // memory), each column's sums still in the order of its rows.  (Tried and slower on the device: the next
+            // block of sixteen rows requested before this one is summed, and the last partial block as a masked block
+            // instead of a row-by-row tail.)
             const double pv = W.piv[nsetp - 1];
             const int applies = (npp1 <= m) && (fabs(pv) > 0.0);
             double bq = up * pv;
             if (applies && bq < 0.0) {
                 bq = 1.0 / bq;
-                PAR_FOR(T, t, iz1 - 1, iz2) {
-                    const int jj = index[t];
-                    double sm = AT(nsetp, jj) * up;
+                dual_ready = true;
+                for (int t = iz1 - 1 + T.tid(); t < iz2; t += 2 * T.size()) {
+                    const int t2 = t + T.size();
+                    const bool two = t2 < iz2;
+                    const int jA = index[t], jB = two ? index[t2] : jA;
+                    const double a0A = AT(nsetp, jA), a0B = AT(nsetp, jB);
+                    double smA = a0A * up, smB = a0B * up, dA = 0.0, dB = 0.0;
                     int r = npp1;
-                    for (; r + 15 <= m; r += 16) {              // loads first, sums in order
-                        double av[16], pv8[16];
+                    for (; r + 15 <= m; r += 16) {
+                        double vA[16], vB[16];
                         SPMD_UNROLL
-                        for (int q = 0; q < 16; ++q) { av[q] = AT(r + q, jj); pv8[q] = W.piv[r - 1 + q]; }
+                        for (int q = 0; q < 16; ++q) { vA[q] = AT(r + q, jA); vB[q] = AT(r + q, jB); }
                         SPMD_UNROLL
-                        for (int q = 0; q < 16; ++q) sm = sm + av[q] * pv8[q];
+                        for (int q = 0; q < 16; ++q) {
+                            const double pq = W.piv[r - 1 + q], br = b[r - 1 + q];
+                            smA = smA + vA[q] * pq;
+                            smB = smB + vB[q] * pq;
+                            if (br != 0.0) { dA = dA + vA[q] * br; dB = dB + vB[q] * br; }
+                        }
                     }
-                    for (; r <= m; ++r) sm = sm + AT(r, jj) * W.piv[r - 1];
-                    if (sm != 0.0) {
+                    for (; r <= m; ++r) {
+                        const double pq = W.piv[r - 1], br = b[r - 1], vA = AT(r, jA), vB = AT(r, jB);
+                        smA = smA + vA * pq;
+                        smB = smB + vB * pq;
+                        if (br != 0.0) { dA = dA + vA * br; dB = dB + vB * br; }
+                    }
+                    // the update of a column whose sum is not zero, and its dual from the new entries
+                    auto update = [&](int jj, double a0, double sm) -> double {
                         sm = sm * bq;
-                        AT(nsetp, jj) = AT(nsetp, jj) + sm * up;
+                        AT(nsetp, jj) = a0 + sm * up;
+                        double d = 0.0;
+                        int r = npp1;
+                        for (; r + 15 <= m; r += 16) {
+                            double v[16];
+                            SPMD_UNROLL
+                            for (int q = 0; q < 16; ++q) v[q] = AT(r + q, jj);
+                            SPMD_UNROLL
+                            for (int q = 0; q < 16; ++q) {
+                                const double an = v[q] + sm * W.piv[r - 1 + q], br = b[r - 1 + q];
+                                AT(r + q, jj) = an;
+                                if (br != 0.0) d = d + an * br;
+                            }
+                        }
+                        for (; r <= m; ++r) {
+                            const double an = AT(r, jj) + sm * W.piv[r - 1], br = b[r - 1];
+                            AT(r, jj) = an;
+                            if (br != 0.0) d = d + an * br;
+                        }
+                        return d;
+                    };
+                    if (two && smA != 0.0 && smB != 0.0) {          // the usual case: both columns together again
+                        smA = smA * bq;
+                        smB = smB * bq;
+                        AT(nsetp, jA) = a0A + smA * up;
+                        AT(nsetp, jB) = a0B + smB * up;
+                        dA = 0.0; dB = 0.0;
                         r = npp1;
                         for (; r + 15 <= m; r += 16) {
-                            double av[16], pv8[16];
+                            double vA[16], vB[16];
                             SPMD_UNROLL
-                            for (int q = 0; q < 16; ++q) { av[q] = AT(r + q, jj); pv8[q] = W.piv[r - 1 + q]; }
+                            for (int q = 0; q < 16; ++q) { vA[q] = AT(r + q, jA); vB[q] = AT(r + q, jB); }
                             SPMD_UNROLL
-                            for (int q = 0; q < 16; ++q) AT(r + q, jj) = av[q] + sm * pv8[q];
+                            for (int q = 0; q < 16; ++q) {
+                                const double pq = W.piv[r - 1 + q], br = b[r - 1 + q];
+                                const double nA = vA[q] + smA * pq, nB = vB[q] + smB * pq;
+                                AT(r + q, jA) = nA;
+                                AT(r + q, jB) = nB;
+                                if (br != 0.0) { dA = dA + nA * br; dB = dB + nB * br; }
+                            }
                         }
-                        for (; r <= m; ++r) AT(r, jj) = AT(r, jj) + sm * W.piv[r - 1];
+                        for (; r <= m; ++r) {
+                            const double pq = W.piv[r - 1], br = b[r - 1];
+                            const double nA = AT(r, jA) + smA * pq, nB = AT(r, jB) + smB * pq;
+                            AT(r, jA) = nA;
+                            AT(r, jB) = nB;
+                            if (br != 0.0) { dA = dA + nA * br; dB = dB + nB * br; }
+                        }
+                    } else {
+                        if (smA != 0.0) dA = update(jA, a0A, smA);
+                        if (two && smB != 0.0) dB = update(jB, a0B, smB);
                     }
+                    w[jA - 1] = dA;
+                    if (two) w[jB - 1] = dB;
                 }
             }
         }
@@ -434,6 +594,7 @@ SPMD_HD int nnls(const Team &T, const Work &W, int mrow, int ncol, int mg, doubl
             iter = W.isc[3];
             if (W.isc[2] == 3) { failed = 1; break; }
             if (W.isc[2] == 0) break;                         // back to L110
+            dual_ready = false;                               // columns leave the set: rows are rotated, the duals are stale
             int jj = W.isc[7];
             int i = index[jj - 1];
             int emptied = 0;
