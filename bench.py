@@ -249,7 +249,7 @@ def qp_algorithmic_bytes(H: int) -> float:
     return 8.0 * (2 * tri + n + m + nz + 2 * n + 2 * n + 2 * mg + 2 * n)
 
 
-def solves_roofline(H, n_qp, solved, seconds):
+def solves_roofline(H, n_qp, solved, seconds, solver_seconds=None):
     """The solves leg against its two bounds, from the committed counter passes of its dominant kernel
     (profiles/rNN/qp_roofline.json: FP64 wavefront instructions, HBM bytes and lane occupancy per QP step over real
     recorded QP subproblems, and the kernel's share of the leg's GPU time from the kernel trace of a full-size solve)
@@ -259,7 +259,9 @@ def solves_roofline(H, n_qp, solved, seconds):
             continue
         share = float(t["share_of_gpu_time"])
         occ = t.get("lane_occupancy") or 1.0
-        kernel_s = seconds * share                         # the leg is one stream of kernels back to back
+        # inside the solver the leg is one stream of kernels back to back (the rest of `seconds` is host-side tick
+        # preparation, unpacking and the gather)
+        kernel_s = (solver_seconds or seconds) * share
         flops = float(t["executed_flops_per_qp"]) * n_qp
         traffic = float(t["traffic_bytes_per_qp"]) * n_qp
         tf = flops / kernel_s / 1e12
@@ -450,7 +452,7 @@ def solve_rate(ctx, mp, sample, threads, rank, world, dist, driver="resident", s
                        "how": "one all_gather of every rank's [count, 9] block, inside the timed region"}
     if driver == "resident":
         # per GPU: every rank runs the same kernels on its own shard, so the fractions are those of one GPU
-        out["roofline"] = solves_roofline(mp.horizon, nqp / world, solved / world, dt_all)
+        out["roofline"] = solves_roofline(mp.horizon, nqp / world, solved / world, dt_all, r.t_serve)
     if device_qp:
         out["rank0_qp_subproblems_on_gpu"] = int(r.n_qp)
         out["rank0_solved_again_on_host"] = int(r.n_host_fallback)
