@@ -1381,6 +1381,24 @@ SPMD_HD inline double jac_column_dot(int H, const double *nz, const double *r, i
     const int j = i / 6, a = i % 6;
     const double *pos = nz + 6 * H + 6 * (j * H - (j * (j - 1)) / 2 - j - 1) + a;       // pos[6 kk] = entry of state kk
     double t = 0.0;
+    if (H <= 24) {
+        // short horizons: every entry of the column and of r is requested before the first addition (one trip to
+        // global memory instead of one per block of eight); entries beyond the column repeat its last one, unused
+        double nv[24], rv[24];
+        const double p1 = pos[6 * (j + 1)], r1 = r[12 * (j + 1) + a], nzi = nz[i], r2 = r[12 * (j + 1) + 6 + a];
+        SPMD_UNROLL
+        for (int q = 0; q < 24; ++q) {
+            const int kk = j + 2 + q <= H ? j + 2 + q : H;
+            nv[q] = pos[6 * kk];
+            rv[q] = r[12 * kk + a];
+        }
+        t = t + p1 * r1;
+        t = t + nzi * r2;
+        SPMD_UNROLL
+        for (int q = 0; q < 24; ++q)
+            if (j + 2 + q <= H) t = t + nv[q] * rv[q];
+        return t;
+    }
     t = t + pos[6 * (j + 1)] * r[12 * (j + 1) + a];
     t = t + nz[i] * r[12 * (j + 1) + 6 + a];
     int kk = j + 2;
@@ -1518,7 +1536,17 @@ SPMD_HD void bfgs_update(const Team &T, const Work &W, int H, double *l, const d
     PAR_FOR(T, i, 0, n) {
         const int off = i * n - (i * (i - 1)) / 2;
         double h1 = 0.0;
-        for (int j = i + 1; j < n; ++j) h1 = h1 + l[off + (j - i)] * s[j];
+        {
+            int j = i + 1;
+            for (; j + 8 <= n; j += 8) {                    // loads first, sum in order
+                double lv[8], sv[8];
+                SPMD_UNROLL
+                for (int q = 0; q < 8; ++q) { lv[q] = l[off + (j + q - i)]; sv[q] = s[j + q]; }
+                SPMD_UNROLL
+                for (int q = 0; q < 8; ++q) h1 = h1 + lv[q] * sv[q];
+            }
+            for (; j < n; ++j) h1 = h1 + l[off + (j - i)] * s[j];
+        }
         double vi = s[i] + h1;
         vi = l[off] * vi;
         vold[i] = vi;
@@ -1526,14 +1554,52 @@ SPMD_HD void bfgs_update(const Team &T, const Work &W, int H, double *l, const d
     T.sync();
     PAR_FOR(T, i, 0, n) {
         double h1 = 0.0;
-        for (int j = 0; j < i; ++j) h1 = h1 + l[j * n - (j * (j - 1)) / 2 + (i - j)] * vold[j];
+        {
+            int j = 0;
+            for (; j + 8 <= i; j += 8) {
+                double lv[8], vv8[8];
+                SPMD_UNROLL
+                for (int q = 0; q < 8; ++q) {
+                    const int jq = j + q;
+                    lv[q] = l[jq * n - (jq * (jq - 1)) / 2 + (i - jq)];
+                    vv8[q] = vold[jq];
+                }
+                SPMD_UNROLL
+                for (int q = 0; q < 8; ++q) h1 = h1 + lv[q] * vv8[q];
+            }
+            for (; j < i; ++j) h1 = h1 + l[j * n - (j * (j - 1)) / 2 + (i - j)] * vold[j];
+        }
         v[i] = vold[i] + h1;
     }
     T.sync();
+    bool summed = false;
+    double h1w = 0.0, h2w = 0.0;
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (Team::kWave) {
+        if (n <= lsqwave::kMaxN) {                          // the two ordered sums as DPP chains on the first wavefront
+            summed = true;
+            if (T.tid() < 64) {
+                const int c16 = lsqwave::lane_here() & 15, pad = lsqwave::kMaxN - n;
+                double P1[8], P2[8];
+                SPMD_UNROLL
+                for (int rr = 0; rr < 8; ++rr) {
+                    const int i = 16 * rr + c16 - pad;
+                    const double si = i >= 0 ? s[i] : 0.0;
+                    P1[rr] = i >= 0 ? si * u[i] : 0.0;
+                    P2[rr] = i >= 0 ? si * v[i] : 0.0;
+                }
+                h1w = lsqwave::ordered_sum_from(0.0, P1, pad);
+                h2w = lsqwave::ordered_sum_from(0.0, P2, pad);
+            }
+        }
+    }
+#endif
     if (T.tid() == 0) {
-        double h1 = 0.0, h2 = 0.0;
-        for (int i = 0; i < n; ++i) h1 = h1 + s[i] * u[i];
-        for (int i = 0; i < n; ++i) h2 = h2 + s[i] * v[i];
+        double h1 = h1w, h2 = h2w;
+        if (!summed) {
+            for (int i = 0; i < n; ++i) h1 = h1 + s[i] * u[i];
+            for (int i = 0; i < n; ++i) h2 = h2 + s[i] * v[i];
+        }
         const double h3 = 0.2 * h2;
         double h4 = 0.0;
         int damp = 0;

@@ -622,6 +622,61 @@ def test_resident_driver_hands_inconsistent_linearisations_to_the_host():
     np.testing.assert_array_equal(two.x, one.x)
 
 
+def test_solve_rounds_reports_a_bound_that_is_too_small_and_leaves_a_finished_solve_alone():
+    """mpc_solve_rounds through the C-ABI: `bound` below the number of unfinished problems is reported as -1 (problems
+    were left out of a round: the solve is void) instead of a silently short count; `bound` = 0 launches nothing and
+    reports the count as it stands; rounds after everything has stopped change nothing."""
+    import ctypes as C
+
+    from helpers import host_scenarios
+    from mpc_amd import _ffi
+    from mpc_amd.batch import MpcContext
+    from mpc_amd.scenarios import to_device
+
+    mp = MpcParams.reference_yaml_defaults(horizon=3)
+    N = 40
+    ctx = MpcContext(mp, N, 0)
+    lib = ctx._lib
+    _, hs = host_scenarios(mp, N, motion="linear", cfg_id=29)
+    sc, _ = to_device(ctx, hs)
+    scc = ctx._scen_c(sc)
+    nbytes = int(lib.mpc_solve_workspace_bytes(3, N))
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=ctx.device)
+    x0 = torch.as_tensor(hs.x).to(ctx.device)
+    left = torch.zeros(1, dtype=torch.int32, device=ctx.device)
+    st = C.c_void_p(torch.cuda.current_stream(ctx.device).cuda_stream)
+    call = lambda fn, *a: _ffi.check(ctx._ctx, fn(ctx._ctx, *a))
+
+    def begin():
+        call(lib.mpc_solve_begin, C.byref(scc), x0.data_ptr(), 1e-3, 50, ws.data_ptr(), N, nbytes, st)
+
+    def rounds(k, bound):
+        call(lib.mpc_solve_rounds, C.byref(scc), ws.data_ptr(), N, nbytes, k, bound, left.data_ptr(), st)
+        return int(left.item())
+
+    begin()
+    assert rounds(1, N) == N                       # every problem asks for its first QP
+    assert rounds(0, N) == N and rounds(3, 0) == N  # nothing launched: the count as it stands
+    assert rounds(1, N // 2) == -1                 # half the problems left out of the round
+    assert rounds(2, N) == -1                      # ... and the flag stays up
+    begin()                                        # a new solve on the same workspace clears it
+    n = N
+    for _ in range(200):
+        n = rounds(6, n)
+        assert n >= 0
+        if n == 0:
+            break
+    assert n == 0
+    out = [torch.empty(N, mp.n, dtype=torch.float64, device=ctx.device), torch.empty(N, dtype=torch.float64, device=ctx.device),
+           torch.empty(N, dtype=torch.int32, device=ctx.device), torch.empty(N, dtype=torch.int32, device=ctx.device)]
+    result = lambda: call(lib.mpc_solve_result, N, ws.data_ptr(), N, nbytes, *(t.data_ptr() for t in out), None, st)
+    result()
+    x1, status1 = out[0].clone(), out[3].clone()
+    assert rounds(6, N) == 0 and rounds(6, 0) == 0  # harmless after the end
+    result()
+    assert torch.equal(out[0], x1) and torch.equal(out[3], status1) and bool((status1 == 0).all())
+
+
 def test_qp_step_rejects_an_index_outside_the_state_rows():
     """mpc_qp_step never addresses state outside [0, rows): such a request gets mode -100 and the valid requests
     of the same call are served as usual."""
