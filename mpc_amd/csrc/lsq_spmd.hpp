@@ -1119,11 +1119,23 @@ SPMD_HD int lsq(const Team &T, const Work &W, int H, const double *g, const doub
     }
     if (T.tid() == 0) W.isc[8] = 1;
     T.sync();
-    PAR_FOR(T, r, 0, n) {
+    // (two indices per row, one for the odd and one for the even columns, eight entries fetched before the first is
+    //  written: a row is up to n entries of LDS, and one thread that reads, scales and writes them one by one pays the
+    //  LDS round trip per entry)
+    PAR_FOR(T, w, 0, 2 * n) {
+        const int r = w >> 1, len = n - r;
         double *er = W.E + EO(r);
         const double d = W.piv[r];
-        er[0] = d;
-        for (int c = 1; c < n - r; ++c) er[c] = d * er[c];
+        if ((w & 1) == 0) er[0] = d;
+        int c = 1 + (w & 1);
+        for (; c + 14 < len; c += 16) {
+            double v[8];
+            SPMD_UNROLL
+            for (int q = 0; q < 8; ++q) v[q] = er[c + 2 * q];
+            SPMD_UNROLL
+            for (int q = 0; q < 8; ++q) er[c + 2 * q] = d * v[q];
+        }
+        for (; c < len; c += 2) er[c] = d * er[c];
     }
     T.sync();
     QP_MARK(T, 0);   // e in place
@@ -1164,30 +1176,57 @@ SPMD_HD int lsq(const Team &T, const Work &W, int H, const double *g, const doub
     QP_MARK(T, 1);   // forward substitution
     // ---- LSI: "QR" of the triangular e (pivot arithmetic only, see slsqp_core.c) applied to f: a row touches
     //      nothing but itself, one row per index
+    //      (first the rows' scalars, pivots and f, one row per index; then the rows' entries, two indices per row as
+    //      above, with the scalars from W.acc, which nothing else uses between the forward substitution and NNLS)
     PAR_FOR(T, i, 0, n - 1) {
         double *er = W.E + EO(i);
         const double eii = er[0];
-        double cl = fabs(eii);
-        if (cl <= 0.0) continue;
-        const double clinv = 1.0 / cl;
-        double sm = (eii * clinv) * (eii * clinv);
-        cl = cl * sqrt(sm);
-        if (eii > 0.0) cl = -cl;
-        const double up = eii - cl;
-        er[0] = cl;
-        double bq = up * cl;
-        if (bq >= 0.0) continue;
-        bq = 1.0 / bq;
-        for (int c = 1; c < n - i; ++c) {
-            sm = er[c] * up;
+        double cl = fabs(eii), up = 0.0, bq = 0.0;
+        if (cl > 0.0) {
+            const double clinv = 1.0 / cl;
+            const double sm = (eii * clinv) * (eii * clinv);
+            cl = cl * sqrt(sm);
+            if (eii > 0.0) cl = -cl;
+            up = eii - cl;
+            er[0] = cl;
+            bq = up * cl;
+            bq = bq < 0.0 ? 1.0 / bq : 0.0;               // 0: the row stays as it is
+        }
+        W.acc[i] = up;
+        W.acc[n + i] = bq;
+        if (bq != 0.0) {
+            double sm = W.ff[i] * up;
+            if (sm != 0.0) {
+                sm = sm * bq;
+                W.ff[i] = W.ff[i] + sm * up;
+            }
+        }
+    }
+    T.sync();
+    PAR_FOR(T, w, 0, 2 * (n - 1)) {
+        const int i = w >> 1, len = n - i;
+        double *er = W.E + EO(i);
+        const double up = W.acc[i], bq = W.acc[n + i];
+        if (bq == 0.0) continue;
+        int c = 1 + (w & 1);
+        for (; c + 14 < len; c += 16) {
+            double v[8];
+            SPMD_UNROLL
+            for (int q = 0; q < 8; ++q) v[q] = er[c + 2 * q];
+            SPMD_UNROLL
+            for (int q = 0; q < 8; ++q) {
+                double sm = v[q] * up;
+                if (sm != 0.0) {
+                    sm = sm * bq;
+                    er[c + 2 * q] = v[q] + sm * up;
+                }
+            }
+        }
+        for (; c < len; c += 2) {
+            double sm = er[c] * up;
             if (sm == 0.0) continue;
             sm = sm * bq;
             er[c] = er[c] + sm * up;
-        }
-        sm = W.ff[i] * up;
-        if (sm != 0.0) {
-            sm = sm * bq;
-            W.ff[i] = W.ff[i] + sm * up;
         }
     }
     T.sync();
