@@ -1500,7 +1500,18 @@ SPMD_HD void ldl(const Team &T, const Work &W, int n, double *a, double *z, doub
         if (T.tid() == 0) {
             double t = sum_in_order(t0, quot, n);
             if (t >= 0.0) t = 2.22e-16 / sigma;
-            for (int j = n; j >= 1; --j) {
+            int j = n;
+            for (; j >= 16; j -= 16) {                      // sixteen terms fetched together, the chain in its order
+                double qv[16];
+                SPMD_UNROLL
+                for (int q = 0; q < 16; ++q) qv[q] = quot[j - 1 - q];
+                SPMD_UNROLL
+                for (int q = 0; q < 16; ++q) {
+                    w[j - 1 - q] = t;
+                    t = t - qv[q];
+                }
+            }
+            for (; j >= 1; --j) {
                 w[j - 1] = t;
                 t = t - quot[j - 1];
             }
@@ -1517,7 +1528,18 @@ SPMD_HD void ldl(const Team &T, const Work &W, int n, double *a, double *z, doub
         T.sync();
         if (T.tid() == 0) {
             double t = t0;
-            for (int i = 0; i < n; ++i) {
+            int i = 0;
+            for (; i + 16 <= n; i += 16) {                  // sixteen terms fetched together, the chain in its order
+                double qv[16];
+                SPMD_UNROLL
+                for (int q = 0; q < 16; ++q) qv[q] = quot[i + q];
+                SPMD_UNROLL
+                for (int q = 0; q < 16; ++q) {
+                    t = t + qv[q];
+                    tpv[i + q] = t;
+                }
+            }
+            for (; i < n; ++i) {
                 t = t + quot[i];
                 tpv[i] = t;
             }
