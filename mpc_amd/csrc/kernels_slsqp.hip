@@ -193,7 +193,7 @@ __global__ void solve_begin_kernel(const mpc_params P, SolveWorkspace W, int cou
     if (i == 0) {
         const size_t p = idx / n;
         W.ACC[p] = acc;
-        W.ITER[p] = maxiter;          // majiter on entry = the iteration limit (_slsqp_py.py:404)
+        W.ITER[p] = maxiter - 1;      // majiter on entry = the iteration limit, maxiter - 1 (_slsqp_py.py:245,392)
         W.MODE[p] = 0;
         W.QPMODE[p] = 0;
         W.QPFLAGS[p] = 0;

@@ -73,61 +73,64 @@ struct SerialTeam {
 
 #define PAR_FOR(T, i, lo, hi) for (int i = (lo) + (T).tid(); i < (hi); i += (T).size())
 
-// Workspace of one team (doubles unless noted).  mg = m + 2n, n1 = n + 1.  Two pools: the BIG one holds the two
+// Workspace of one team (doubles unless noted), sized for Kraft's augmented problem (one variable more: n + 1
+// variables, two more bound rows): mga = m + 2n + 2 rows of [g h], n2 = n + 2 columns (the variables and h).  The
+// plain problem uses mg = m + 2n and n + 1 of them.  Two pools: the BIG one holds the two
 // matrices and lives in global memory; the SMALL one (the packed triangle and every vector) is what the serial
 // sections and the broadcast reads touch, and goes to LDS when it fits (kernels_qp.hip).
 struct Work {
-    double *G;     // [(n+1)*mg]: G[i + j*mg] = g(i, j) for j < n; G[i + n*mg] = h(i)
-    double *AT;    // [(n+1)*mg]: the copy NNLS works on and overwrites (LDP needs g and h again afterwards)
+    double *G;     // [n2*mga]: G[i + j*ld] = g(i, j) for j < N; G[i + N*ld] = h(i)  (N variables, ld rows: n, mg or n + 1, mga)
+    double *AT;    // [n2*mga]: the copy NNLS works on and overwrites (LDP needs g and h again afterwards)
     double *E;     // [n(n+1)/2 + 1]: on entry the packed LDL' factor l; lsq turns it IN PLACE into e = sqrt(d) l^T,
-                   // e(r, c) for r <= c at E[off(r) + c - r], off(r) = r n - r(r-1)/2 (0-based), i.e. row by row
+                   // e(r, c) for r <= c at E[off(r) + c - r], off(r) = r n - r(r-1)/2 (0-based), i.e. row by row;
+                   // the last entry is the augmented problem's e(n, n) = rho (Kraft's l(n3)), unused otherwise
     double *ff;    // [n]
-    double *acc;   // [max(mg, team size)]; NNLS's reduction (redv) borrows it
-    double *bb;    // [n1]  NNLS right-hand side
-    double *zz;    // [n1]
-    double *xn;    // [mg]  NNLS solution (dual variables of LDP)
-    double *wd;    // [mg]  NNLS dual vector
-    double *piv;   // [n1]  copy of the pivot column
-    double *xs;    // [n]
+    double *acc;   // [max(mga, team size)]; NNLS's reduction (redv) borrows it
+    double *bb;    // [n2]  NNLS right-hand side
+    double *zz;    // [n2]
+    double *xn;    // [mga]  NNLS solution (dual variables of LDP)
+    double *wd;    // [mga]  NNLS dual vector
+    double *piv;   // [n2]  copy of the pivot column
+    double *xs;    // [n + 1]
     double *sc;    // [16]  scalars broadcast from thread 0
     double *redv;  // = acc
-    int *redi;     // [max(team size, n1)]: NNLS's reduction; afterwards the final set, sorted
-    int *idx;      // [mg]
+    int *redi;     // [max(team size, n2)]: NNLS's reduction; afterwards the final set, sorted
+    int *idx;      // [mga]
     int *isc;      // [16]
 };
 
-SPMD_HD inline size_t big_doubles(int n, int m) { return 2 * ((size_t)n + 1) * ((size_t)m + 2 * (size_t)n); }
+SPMD_HD inline size_t big_doubles(int n, int m) { return 2 * ((size_t)n + 2) * ((size_t)m + 2 * (size_t)n + 2); }
 SPMD_HD inline size_t small_doubles(int n, int m, int team)
 {
-    const size_t mg = (size_t)m + 2 * (size_t)n, n1 = (size_t)n + 1;
-    const size_t accn = mg > (size_t)team ? mg : (size_t)team;
-    return (size_t)n * n1 / 2 + 1 + n + accn + n1 + n1 + mg + mg + n1 + n + 16;
+    const size_t mga = (size_t)m + 2 * (size_t)n + 2, n2 = (size_t)n + 2;
+    const size_t accn = mga > (size_t)team ? mga : (size_t)team;
+    return (size_t)n * (n + 1) / 2 + 1 + n + accn + n2 + n2 + mga + mga + n2 + (n + 1) + 16;
 }
 SPMD_HD inline size_t work_doubles(int n, int m, int team) { return big_doubles(n, m) + small_doubles(n, m, team); }
 SPMD_HD inline size_t work_ints(int n, int m, int team)
 {
-    return (size_t)(team > n + 1 ? team : n + 1) + (size_t)m + 2 * (size_t)n + 16;
+    return (size_t)(team > n + 2 ? team : n + 2) + (size_t)m + 2 * (size_t)n + 2 + 16;
 }
 
 SPMD_HD inline Work carve(double *big, double *d, int *i, int n, int m, int team)
 {
-    const size_t mg = (size_t)m + 2 * (size_t)n, n1 = (size_t)n + 1;
+    const size_t mga = (size_t)m + 2 * (size_t)n + 2, n2 = (size_t)n + 2;
     Work W;
     W.G = big;
-    W.AT = big + n1 * mg;
-    W.E = d;            d += (size_t)n * n1 / 2 + 1;
+    W.AT = big + n2 * mga;
+    W.E = d;            d += (size_t)n * (n + 1) / 2 + 1;
     W.ff = d;           d += n;
-    W.acc = d;          d += mg > (size_t)team ? mg : (size_t)team;
-    W.bb = d;           d += n1;
-    W.zz = d;           d += n1;
-    W.xn = d;           d += mg;
-    W.wd = d;           d += mg;
-    W.piv = d;          d += n1;
-    W.xs = d;           d += n;
+    W.acc = d;          d += mga > (size_t)team ? mga : (size_t)team;
+    W.bb = d;           d += n2;
+    W.zz = d;           d += n2;
+    W.xn = d;           d += mga;
+    W.wd = d;           d += mga;
+    W.piv = d;          d += n2;
+    W.xs = d;           d += n + 1;
     W.sc = d;
     W.redv = W.acc;
-    W.redi = i;         i += team > n + 1 ? team : n + 1;
-    W.idx = i;          i += mg;
+    W.redi = i;         i += team > n + 2 ? team : n + 2;
+    W.idx = i;          i += mga;
     W.isc = i;
     return W;
 }
@@ -713,7 +716,10 @@ struct RowDesc {
 // by one pass of the whole team after the transform (contiguous loads and stores, 960 bytes per column).
 SPMD_HD inline double twin_of(double v) { return 0.0 - v; }
 
-SPMD_HD inline RowDesc describe_row(int H, int i, const double *cvals, const double *lo, const double *hi)
+// aug: the rows are numbered as in Kraft's augmented problem (one more variable, delta, whose two bound rows follow
+// the lower and the upper bounds of the others: m constraint rows, n + 1 lower bounds, n + 1 upper bounds); delta's own
+// rows are not described here (delta_row below writes them).
+SPMD_HD inline RowDesc describe_row(int H, int i, const double *cvals, const double *lo, const double *hi, int aug = 0)
 {
     const int n = 6 * H, m = 12 * (H + 1);
     RowDesc d;
@@ -727,7 +733,7 @@ SPMD_HD inline RowDesc describe_row(int H, int i, const double *cvals, const dou
         const int v = i - m;
         d.a = v % 6; d.first = v / 6; d.last = d.first; d.kind = 3; d.hval = lo[v]; d.hval_twin = -hi[v];
     } else {
-        const int v = i - m - n;
+        const int v = i - m - n - aug;
         d.a = v % 6; d.first = v / 6; d.last = d.first; d.kind = 4; d.hval = -hi[v];
     }
     return d;
@@ -977,19 +983,24 @@ SPMD_HD inline int work_order(int H, int p)
     return q - 12 * H;
 }
 
-template <int R, bool COOP = false>
+// AUG (Kraft's augmented problem, slsqp_core.c's lsq with n2 = 1): one more variable, delta, whose row of e is
+// (0, ..., 0, rho) with f = -0.0.  A row of g gets one more entry, (a(i, n + 1) - 0) / rho with a(i, n + 1) =
+// max(-c(i), 0) in a constraint row and 0 in a bound row: the sum that is subtracted runs over products with the
+// zeros of e's last column and stays +0.0; the row's h is what it was, its last term g(i, n + 1) * (-0.0) leaves a sum
+// that is never -0.0 as it is.  h moves one place down (column n + 1), rows are mg + 2 apart, the twins n + 1 further.
+template <int R, bool COOP = false, bool AUG = false>
 SPMD_HD inline void transform_rows(const Work &W, int H, const int *rows, const double *cvals, const double *nz,
                                    const double *lo, const double *hi, double *const *dst, bool store = true,
                                    double *base = nullptr,      // COOP: dst[r] = base + rows[r], base the same in every lane
                                    bool twin = false)           // also write the twin's h (row + n, column n) of every lower-bound row
 {
-    const int n = 6 * H, mg = 12 * (H + 1) + 2 * n;
+    const int n = 6 * H, mg = 12 * (H + 1) + 2 * n + (AUG ? 2 : 0);        // mg: the distance between two columns
     RowDesc d[R];
     double th[R];
     int first_any = H;
     SPMD_UNROLL
     for (int r = 0; r < R; ++r) {
-        d[r] = describe_row(H, rows[r], cvals, lo, hi);
+        d[r] = describe_row(H, rows[r], cvals, lo, hi, AUG ? 1 : 0);
         th[r] = 0.0;
         first_any = d[r].first < first_any ? d[r].first : first_any;
     }
@@ -1033,10 +1044,27 @@ SPMD_HD inline void transform_rows(const Work &W, int H, const int *rows, const 
     if (store) {
         SPMD_UNROLL
         for (int r = 0; r < R; ++r) {
-            dst[r][(size_t)n * mg] = d[r].hval - th[r];
-            if (twin && d[r].kind == 3) dst[r][(size_t)n * mg + n] = d[r].hval_twin - twin_of(th[r]);
+            if constexpr (AUG) {
+                const double last = (rows[r] < 12 * (H + 1) && d[r].hval > 0.0) ? d[r].hval : 0.0;     // max(-c, 0) / 0
+                dst[r][(size_t)n * mg] = (last - 0.0) / W.E[(n * (n + 1)) / 2];
+                dst[r][(size_t)(n + 1) * mg] = d[r].hval - th[r];
+                if (twin && d[r].kind == 3) dst[r][(size_t)(n + 1) * mg + n + 1] = d[r].hval_twin - twin_of(th[r]);
+            } else {
+                dst[r][(size_t)n * mg] = d[r].hval - th[r];
+                if (twin && d[r].kind == 3) dst[r][(size_t)n * mg + n] = d[r].hval_twin - twin_of(th[r]);
+            }
         }
     }
+}
+
+// The two bound rows of the augmented problem's extra variable (0 <= delta <= 1): row `upper` ? -e_{n+1} : +e_{n+1}
+// of g, transformed: zeros before the last entry, (0 - 0) / e(j, j) each; the last (+-1 - 0) / rho; h = 0 or -1 minus a sum
+// of zeros that ends +0.0.  One thread writes a row (n + 2 entries, ld apart).
+SPMD_HD inline void delta_row(const Work &W, int n, int ld, bool upper, double *dst)
+{
+    for (int j = 0; j < n; ++j) dst[(size_t)j * ld] = (0.0 - 0.0) / W.E[j * n - (j * (j - 1)) / 2];
+    dst[(size_t)n * ld] = ((upper ? -1.0 : 1.0) - 0.0) / W.E[(n * (n + 1)) / 2];
+    dst[(size_t)(n + 1) * ld] = (upper ? -1.0 : 0.0) - 0.0;
 }
 
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -1104,11 +1132,21 @@ __device__ __attribute__((noinline)) void transform_rows_call(const double *E, c
 //     +0.0, which leaves +0.0;
 //   * sums against the NNLS solution skip its exact zeros (every entry outside the final set): t + a * 0.0 is t for
 //     finite a, and t is never -0.0.
-template <class Team>
+//
+// AUG: Kraft's augmented problem for an inconsistent linearisation (slsqp_body.inc, the block after the QP returns
+// mode 4; slsqp_core.c's lsq with n2 = 1): one more variable delta in [0, 1] with the column max(-c, 0) in the
+// constraint rows and the weight rho = W.E[n(n+1)/2] (Kraft's l(n3)) as its row of e.  N = n + 1 variables, two more
+// bound rows (delta's lower bound follows the other lower bounds, its upper bound the other upper bounds), the rows
+// of [g h] ld = mg + 2 apart; *delta receives the last entry of the step.  What the extra row and column of e
+// contribute to the sums of the other variables are products with exact zeros at the end of sums that are never
+// -0.0 (delta finite): those terms are left out, every other operation is the serial text's.
+template <bool AUG = false, class Team>
 SPMD_HD int lsq(const Team &T, const Work &W, int H, const double *g, const double *cvals, const double *nz, const double *lo,
-                const double *hi, double *s, double *y)
+                const double *hi, double *s, double *y, double *delta = nullptr)
 {
+    static_assert(!AUG || MPC_QP_ROWS == 1, "the augmented transform is written for one row per lane");
     const int n = 6 * H, m = 12 * (H + 1), mg = m + 2 * n;
+    const int N = n + (AUG ? 1 : 0), ld = mg + (AUG ? 2 : 0);
 #define EO(r) ((r) * n - ((r) * ((r) - 1)) / 2)
     QP_MARK_START(T);
     // ---- e = sqrt(d) l^T in place (row r of e is column r of l scaled by sqrt(d_r))
@@ -1178,7 +1216,8 @@ SPMD_HD int lsq(const Team &T, const Work &W, int H, const double *g, const doub
     //      nothing but itself, one row per index
     //      (first the rows' scalars, pivots and f, one row per index; then the rows' entries, two indices per row as
     //      above, with the scalars from W.acc, which nothing else uses between the forward substitution and NNLS)
-    PAR_FOR(T, i, 0, n - 1) {
+    // (the last row has nothing to its right and is left alone, unless the augmented problem's row follows it)
+    PAR_FOR(T, i, 0, N - 1) {
         double *er = W.E + EO(i);
         const double eii = er[0];
         double cl = fabs(eii), up = 0.0, bq = 0.0;
@@ -1230,8 +1269,8 @@ SPMD_HD int lsq(const Team &T, const Work &W, int H, const double *g, const doub
         }
     }
     T.sync();
-    PAR_FOR(T, j, 0, n)
-        if (!(fabs(W.E[EO(j)]) >= 2.22e-16)) W.isc[8] = 0;
+    PAR_FOR(T, j, 0, N)
+        if (!(fabs(W.E[EO(j)]) >= 2.22e-16)) W.isc[8] = 0;       // (EO(n) is where rho sits)
     T.sync();
     if (!W.isc[8]) return 5;
     QP_MARK(T, 2);   // QR rows
@@ -1288,42 +1327,48 @@ SPMD_HD int lsq(const Team &T, const Work &W, int H, const double *g, const doub
                                                                  rows[MPC_QP_ROWS - 1], mine ? 1 : 0);
             } else
 #endif
-                transform_rows<MPC_QP_ROWS, true>(W, H, rows, cvals, nz, lo, hi, dst, mine, W.AT, true);
+                transform_rows<MPC_QP_ROWS, true, AUG>(W, H, rows, cvals, nz, lo, hi, dst, mine, W.AT, true);
         }
+    }
+    if constexpr (AUG) {
+        PAR_FOR(T, q, 0, 2) delta_row(W, n, ld, q == 1, W.AT + (q == 0 ? m + n : m + n + N));
     }
     T.sync();
     // the upper-bound rows: twins of the lower-bound rows (eight loads in flight per thread: the matrix is in global memory)
-    for (int e0 = T.tid(); e0 < n * n; e0 += 8 * T.size()) {
+    for (int e0 = T.tid(); e0 < n * N; e0 += 8 * T.size()) {
         double v[8];
         SPMD_UNROLL
         for (int q = 0; q < 8; ++q) {
             const int e = e0 + q * T.size(), j = e / n;
-            v[q] = e < n * n ? W.AT[(size_t)j * mg + m + (e - j * n)] : 0.0;
+            v[q] = e < n * N ? W.AT[(size_t)j * ld + m + (e - j * n)] : 0.0;
         }
         SPMD_UNROLL
         for (int q = 0; q < 8; ++q) {
             const int e = e0 + q * T.size(), j = e / n;
-            if (e < n * n) W.AT[(size_t)j * mg + m + n + (e - j * n)] = twin_of(v[q]);
+            if (e < n * N) W.AT[(size_t)j * ld + m + N + (e - j * n)] = twin_of(v[q]);
         }
     }
     QP_MARK(T, 3);   // transform
-    // ---- LDP: NNLS on the copy of [g h]^T with right-hand side e_{n+1}
-    PAR_FOR(T, i, 0, n) W.bb[i] = 0.0;
-    if (T.tid() == 0) W.bb[n] = 1.0;
+    // ---- LDP: NNLS on the copy of [g h]^T with right-hand side e_{N+1}
+    PAR_FOR(T, i, 0, N) W.bb[i] = 0.0;
+    if (T.tid() == 0) W.bb[N] = 1.0;
     T.sync();
     double rnorm = 0.0;
-    int mode = nnls(T, W, n + 1, mg, mg, &W.sc[2]);
+    int mode = nnls(T, W, N + 1, ld, ld, &W.sc[2]);
     T.sync();
     rnorm = W.sc[2];
     if (mode != 1) return mode;
     if (rnorm <= 0.0) return 4;
     QP_MARK(T, 4);   // NNLS
     // ---- the rows of the transformed [g h] that are in the final set (NNLS overwrote its copy): computed again
-    PAR_FOR(T, i, 0, mg)
+    PAR_FOR(T, i, 0, ld)
         if (W.xn[i] != 0.0) {
-            const int rows[1] = {i};
-            double *const dst[1] = {W.G + i};
-            transform_rows<1>(W, H, rows, cvals, nz, lo, hi, dst);
+            if (AUG && (i == m + n || i == ld - 1)) delta_row(W, n, ld, i == ld - 1, W.G + i);
+            else {
+                const int rows[1] = {i};
+                double *const dst[1] = {W.G + i};
+                transform_rows<1, false, AUG>(W, H, rows, cvals, nz, lo, hi, dst);
+            }
         }
     T.sync();
     QP_MARK(T, 5);   // final-set rows
@@ -1339,8 +1384,8 @@ SPMD_HD int lsq(const Team &T, const Work &W, int H, const double *g, const doub
         }
     }
     T.sync();
-    PAR_FOR(T, j, 0, n + 1) {
-        const double *gj = W.G + (size_t)j * mg;
+    PAR_FOR(T, j, 0, N + 1) {
+        const double *gj = W.G + (size_t)j * ld;
         double t = 0.0;
         for (int q = 0; q < nset; ++q) {
             const int i = W.redi[q];
@@ -1351,7 +1396,7 @@ SPMD_HD int lsq(const Team &T, const Work &W, int H, const double *g, const doub
     }
     T.sync();
     if (T.tid() == 0) {
-        const double fac = 1.0 - W.zz[n];                 // 1 - ddot(m, h, y)
+        const double fac = 1.0 - W.zz[N];                 // 1 - ddot(m, h, y)
         volatile double d = 1.0 + fac;
         W.isc[9] = (d - 1.0 > 0.0) ? 1 : 0;
         W.sc[3] = fac;
@@ -1359,14 +1404,20 @@ SPMD_HD int lsq(const Team &T, const Work &W, int H, const double *g, const doub
     T.sync();
     if (!W.isc[9]) return 4;
     const double fac = 1.0 / W.sc[3];
-    PAR_FOR(T, j, 0, n) W.xs[j] = fac * W.zz[j];
-    PAR_FOR(T, i, 0, mg) y[i] = 0.0 + fac * W.xn[i];
+    PAR_FOR(T, j, 0, N) W.xs[j] = fac * W.zz[j];
+    PAR_FOR(T, i, 0, mg) y[i] = 0.0 + fac * W.xn[i];       // (augmented: the bound rows' places are shifted; nobody reads them)
     T.sync();
     QP_MARK(T, 6);   // column sums
     // ---- back to the original variables: x = e^-1 (x + f) by back substitution, then the box.  Row i's sum runs
     //      over j = i + 1, i + 2, ... while x(j) becomes known in the opposite order, so the sum itself is a serial
     //      chain (thread 0); the products are formed by the team first.
     PAR_FOR(T, i, 0, n) W.xs[i] = W.xs[i] + 1.0 * W.ff[i];
+    if constexpr (AUG) {                                   // delta first: f = -0.0, an empty sum, e(n, n) = rho
+        if (T.tid() == 0) {
+            const double xd = W.xs[n] + 1.0 * -0.0;
+            W.xs[n] = (xd - 0.0) / W.E[EO(n)];
+        }
+    }
     T.sync();
     // Row i needs the products e(i, j) x(j), j > i, added in ascending j.  The whole recurrence runs on the team's
     // first wavefront alone (up to 64 threads form the products, its first thread adds them up): what one wavefront
@@ -1406,6 +1457,14 @@ SPMD_HD int lsq(const Team &T, const Work &W, int H, const double *g, const doub
         if (v < lo[i]) v = lo[i];
         else if (v > hi[i]) v = hi[i];
         s[i] = v;
+    }
+    if constexpr (AUG) {
+        if (T.tid() == 0) {
+            double v = W.xs[n];
+            if (v < 0.0) v = 0.0;
+            else if (v > 1.0) v = 1.0;
+            *delta = v;
+        }
     }
     T.sync();
     QP_MARK(T, 7);   // back substitution + box

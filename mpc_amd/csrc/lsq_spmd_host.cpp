@@ -12,17 +12,26 @@ extern "C" {
 int mpc_lsq_spmd_nnls_iterations = 0;
 }
 
+// diagnostic: how many of the calls so far were Kraft's augmented problem (tests make sure the case was met)
+extern "C" {
+int mpc_lsq_spmd_augmented_calls = 0;
+}
+
 extern "C" void mpc_lsq_spmd_serial(int m, int meq, int n, int nl, int la, double *l, double *g, double *a, double *b,
                                     double *xl, double *xu, double *x, double *y, double *w, int *jw, int *mode)
 {
-    const int H = n / 6;
-    if (meq != 0 || n != 6 * H || m != 12 * (H + 1) || nl != (n + 1) * n / 2 + 1) {   // e.g. the augmented problem
+    // the plain problem has n = 6H variables and the whole factor; the augmented one n = 6H + 1 (the last in [0, 1])
+    // and the factor of the first 6H with rho behind it
+    const bool plain = n % 6 == 0 && nl == (n + 1) * n / 2 + 1;
+    const bool aug = n % 6 == 1 && nl == n * (n - 1) / 2 + 1 && xl[n - 1] == 0.0 && xu[n - 1] == 1.0;
+    const int nv = aug ? n - 1 : n, H = nv / 6;
+    if (meq != 0 || !(plain || aug) || H < 1 || m != 12 * (H + 1)) {
         mpc_slsqp_lsq_builtin(m, meq, n, nl, la, l, g, a, b, xl, xu, x, y, w, jw, mode);
         return;
     }
-    const int nzc = 6 * H + 3 * H * (H + 1), mg = m + 2 * n;
-    std::vector<double> nz(nzc), dw(lsqspmd::work_doubles(n, m, 1)), yy(mg);
-    std::vector<int> iw(lsqspmd::work_ints(n, m, 1));
+    const int nzc = 6 * H + 3 * H * (H + 1), mg = m + 2 * nv;
+    std::vector<double> nz(nzc), dw(lsqspmd::work_doubles(nv, m, 1)), yy(mg);
+    std::vector<int> iw(lsqspmd::work_ints(nv, m, 1));
     for (int j = 0; j < H; ++j) {
         const int tri = j * H - (j * (j - 1)) / 2 - j - 1;
         for (int q = 0; q < 6; ++q) {
@@ -31,13 +40,18 @@ extern "C" void mpc_lsq_spmd_serial(int m, int meq, int n, int nl, int la, doubl
             for (int k = j + 1; k <= H; ++k) nz[6 * H + 6 * (tri + k) + q] = a[(12 * k + q) + (size_t)col * la];
         }
     }
-    lsqspmd::Work W = lsqspmd::carve(dw.data(), dw.data() + lsqspmd::big_doubles(n, m), iw.data(), n, m, 1);
+    lsqspmd::Work W = lsqspmd::carve(dw.data(), dw.data() + lsqspmd::big_doubles(nv, m), iw.data(), nv, m, 1);
     for (int e = 0; e < nl; ++e) W.E[e] = l[e];                  // lsq works on its own copy of the factor
-    *mode = lsqspmd::lsq(lsqspmd::SerialTeam(), W, H, g, b, nz.data(), xl, xu, x, yy.data());
+    if (aug) {
+        mpc_lsq_spmd_augmented_calls++;
+        *mode = lsqspmd::lsq<true>(lsqspmd::SerialTeam(), W, H, g, b, nz.data(), xl, xu, x, yy.data(), &x[nv]);
+    } else {
+        *mode = lsqspmd::lsq(lsqspmd::SerialTeam(), W, H, g, b, nz.data(), xl, xu, x, yy.data());
+    }
     mpc_lsq_spmd_nnls_iterations = W.isc[3];
     if (*mode == 1) {
         for (int i = 0; i < m; ++i) y[i] = yy[i];
-        for (int i = m; i < m + 2 * n; ++i) y[i] = NAN;
+        for (int i = m; i < m + 2 * nv; ++i) y[i] = NAN;
     }
 }
 

@@ -101,7 +101,7 @@ int mpc_slsqp_begin(mpc_slsqp_batch *b, int count, const double *x0, const doubl
             x[i] = v;
         }
         b->acc[p] = acc;
-        b->iter[p] = maxiter;          /* majiter on entry = the iteration limit (_slsqp_py.py:404) */
+        b->iter[p] = maxiter - 1;      /* majiter on entry = the iteration limit, maxiter - 1 (_slsqp_py.py:245,392) */
         b->mode[p] = 0;
         b->done[p] = 0;
         memset(&b->st[p], 0, sizeof(slsqp_state));

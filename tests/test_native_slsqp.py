@@ -41,13 +41,16 @@ def _scipy_core_solve(co, hs, i, mp, lb, ub, x0):
     return p, hist
 
 
-@pytest.mark.parametrize("H,N,motion,prev", [(1, 12, "linear", False), (3, 10, "angular", True), (20, 5, "angular", False),
-                                            (40, 2, "linear", True)])
-def test_native_batch_reproduces_scipy_core_call_by_call(H, N, motion, prev):
+@pytest.mark.parametrize("H,N,motion,prev,bad", [(1, 12, "linear", False, ()), (3, 10, "angular", True, ()),
+                                                (20, 5, "angular", False, ()), (40, 2, "linear", True, ()),
+                                                (3, 6, "angular", False, (0, 3, 4)), (20, 3, "linear", False, (1,))])
+def test_native_batch_reproduces_scipy_core_call_by_call(H, N, motion, prev, bad):
     """Every round of the native driver leaves every problem exactly where scipy's core leaves it after the
-    same number of calls: same mode, bit-identical x; same exit mode, iteration count and f at the end."""
+    same number of calls: same mode, bit-identical x; same exit mode, iteration count and f at the end.
+    `bad`: scenarios that start with a joint beyond its limit (inconsistent linearisation: Kraft's augmented problem)."""
     mp = params_for(H)
     co, hs = host_scenarios(mp, N, motion=motion, cfg_id=41, with_prev=prev, goal_jitter=0.0 if H == 20 else 0.05)
+    hs.state0[list(bad), 0] = mp.q_limit + 0.2
     n, m = mp.n, mp.m
     lb = np.array([b[0] for b in mp.bounds()])
     ub = np.array([b[1] for b in mp.bounds()])
@@ -97,10 +100,13 @@ def test_native_batch_argument_checks():
     b.close()
 
 
-@pytest.mark.parametrize("H,N", [(1, 8), (3, 8), (20, 4)])
-def test_team_parallel_lsq_with_a_team_of_one_keeps_whole_solves_identical(H, N):
+@pytest.mark.parametrize("H,N,bad", [(1, 8, ()), (3, 8, ()), (20, 4, ()), (1, 6, (1, 4)), (3, 8, (2, 5)), (20, 4, (1,))])
+def test_team_parallel_lsq_with_a_team_of_one_keeps_whole_solves_identical(H, N, bad):
     """lsq_spmd.hpp is the QP subproblem written for a team of threads (the form a GPU workgroup runs).  With a
-    team of one, hooked into the C core in place of its own LSQ, whole solves must not move by a bit."""
+    team of one, hooked into the C core in place of its own LSQ, whole solves must not move by a bit.
+    `bad`: scenarios whose first joint starts beyond its limit: a constraint row is negative with a zero gradient, the
+    linearisation is inconsistent and the body turns to Kraft's augmented problem (one more variable), which the team
+    code solves as well (lsq<AUG>)."""
     import ctypes
 
     from mpc_amd import native_solver
@@ -108,6 +114,9 @@ def test_team_parallel_lsq_with_a_team_of_one_keeps_whole_solves_identical(H, N)
     lib = native_solver.load()
     mp = params_for(H)
     co, hs = host_scenarios(mp, N, motion="angular", cfg_id=42, goal_jitter=0.0 if H == 20 else 0.05)
+    hs.state0[list(bad), 0] = mp.q_limit + 0.2
+    aug_calls = ctypes.c_int.in_dll(lib, "mpc_lsq_spmd_augmented_calls")
+    aug_before = aug_calls.value
     n = mp.n
     lb = np.array([b[0] for b in mp.bounds()])
     ub = np.array([b[1] for b in mp.bounds()])
@@ -143,6 +152,7 @@ def test_team_parallel_lsq_with_a_team_of_one_keeps_whole_solves_identical(H, N)
     finally:
         lib.mpc_slsqp_set_lsq(None)
         lib.mpc_slsqp_set_bfgs(None)
+    assert (aug_calls.value > aug_before) == bool(bad)
     assert len(got[0]) == len(want[0])
     for (xa, ma), (xb, mb) in zip(got[0], want[0]):
         np.testing.assert_array_equal(ma, mb)
