@@ -227,7 +227,9 @@ int mpc_qp_solve(mpc_ctx *ctx, int count, const double *l, const double *g, cons
  * the problem's current iterate).  Per request (position k in the list): flags, lo, hi, s_in [n] in;
  * s_out [n], r_out [m] (constraint multipliers), mode out.  Bit-identical to the host core.
  * The indices must be distinct (two requests for one problem would race on its state).  A request whose index lies
- * outside [0, rows) touches no state and gets mode -100. */
+ * outside [0, rows) touches no state and gets mode -100.  A request with flags bit 2 (Kraft's augmented problem for an
+ * inconsistent linearisation, mpc_amd/csrc/slsqp_core.h) is not served by this call and gets mode -101: the
+ * device-resident solve below serves such requests, a host-side caller solves that problem with the host driver. */
 int mpc_qp_step(mpc_ctx *ctx, int count, int rows, const int32_t *index, const int32_t *flags, const double *lo,
                 const double *hi, const double *s_in, double *L, const double *G, const double *C, const double *NZ, double *R,
                 double *V, double *s_out, double *r_out, int32_t *mode, void *stream);
@@ -252,7 +254,10 @@ int mpc_qp_step(mpc_ctx *ctx, int count, int rows, const int32_t *index, const i
  *       more requests than `bound` sized its grids for (problems were left out: the solve is void, begin again).
  *       If a launch fails part-way the call returns MPC_ERR_HIP and the workspace is forgotten: further rounds and
  *       mpc_solve_result are refused until mpc_solve_begin has run again.  A problem whose linearisation
- *       is inconsistent stops with status 104 (solve it again with the host driver, include/mpc_slsqp.h).
+ *       is inconsistent (QP mode 4) goes on with Kraft's augmented problem on the device, as in the host core
+ *       (slsqp_body.inc: one more variable, weight 100 .. 1e7): such QPs are solved by a kernel of their own, which
+ *       the rounds launch from the first call on that finds the flag up which the QP kernel raises (a word of
+ *       pinned host memory) when it meets one; until then the problem waits, asking again every round.
  *   mpc_solve_result: x [N][n], fun [N], nit [N], status [N] (SLSQP's exit mode, 0 = converged) and, if non-NULL,
  *       stats[4] = {mpc_eval requests, mpc_eval_fd_nz requests, QP steps, unfinished in the last round} (device).
  * `sc` must be the same batch in all three calls; calls on one context / one workspace must not overlap. */

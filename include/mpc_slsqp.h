@@ -63,7 +63,12 @@ int mpc_slsqp_advance(mpc_slsqp_batch *b, int32_t *want_f, int32_t *n_want_f, in
  * last step, input of the BFGS update) and qp_flags (bit 0: reset the factor to the identity first, bit 1: update it
  * with the new derivatives first), and writes the new step into s, the m constraint multipliers into r
  * (rows [m + 2n + 2]) and the QP's mode into qp_mode.  In this mode the host needs f, c (mode 1) and grad f
- * (mode -1) only: dc/dx stays with the caller. */
+ * (mode -1) only: dc/dx stays with the caller.
+ * on = 1: a problem whose linearisation is inconsistent (QP mode 4) ends with mode 104 and is to be solved again
+ * without offload.  on = 2: the caller takes Kraft's augmented problem as well: such a problem asks again with
+ * qp_flags bit 2 set and the weight's exponent k in bits 3..5 (one more variable in [0, 1], column max(-c, 0),
+ * weight 100 * 10^k; no reset, no update); the caller answers as before and puts the extra variable's step into
+ * r[m].  (mpc_qp_step_serial, a team of one on the host, serves both kinds of request: tests use it.) */
 int mpc_slsqp_set_offload(mpc_slsqp_batch *b, int on);
 int mpc_slsqp_advance_qp(mpc_slsqp_batch *b, int32_t *want_f, int32_t *n_want_f, int32_t *want_g, int32_t *n_want_g,
                          int32_t *want_q, int32_t *n_want_q);

@@ -5,6 +5,7 @@
 // p = blockIdx.x, blockIdx.x + gridDim.x, ...), each with its own slice of the workspace.
 #include "lsq_spmd.hpp"
 #include "mpc_kernels.hpp"
+#include "slsqp_core.h"
 
 // Teams of 256 threads, two per CU (LDS), hence two waves per SIMD and 256 VGPRs per wave: the row transform keeps
 // its 2 x 12 accumulators, the row's earlier entries and a row of e in registers without spilling (with 512-thread
@@ -49,16 +50,18 @@ extern __shared__ double qp_lds[];
 // LDS when the launch gave it room for them (lds != 0), else in the same slice.
 // (A template parameter, not a run-time switch: with one origin per pointer the compiler addresses the small pool
 // with LDS instructions instead of flat ones.)
+// aug: the layout of Kraft's augmented problem (one variable and two rows more); the slices are sized for it.
 template <bool kLds>
-__device__ lsqspmd::Work team_work(double *work, int *iwork, size_t wd, size_t wi, int n, int m)
+__device__ lsqspmd::Work team_work(double *work, int *iwork, size_t wd, size_t wi, int n, int m, int aug = 0)
 {
     double *big = work + (size_t)blockIdx.x * wd;
     if constexpr (!kLds) {
-        return lsqspmd::carve(big, big + lsqspmd::big_doubles(n, m), iwork + (size_t)blockIdx.x * wi, n, m, (int)blockDim.x);
+        return lsqspmd::carve(big, big + lsqspmd::big_doubles(n, m, aug), iwork + (size_t)blockIdx.x * wi, n, m,
+                              (int)blockDim.x, aug);
     } else {
         double *small = qp_lds;
-        return lsqspmd::carve(big, small, reinterpret_cast<int *>(small + lsqspmd::small_doubles(n, m, (int)blockDim.x)), n, m,
-                              (int)blockDim.x);
+        return lsqspmd::carve(big, small, reinterpret_cast<int *>(small + lsqspmd::small_doubles(n, m, (int)blockDim.x, aug)), n,
+                              m, (int)blockDim.x, aug);
     }
 }
 
@@ -88,21 +91,28 @@ qp_kernel(int H, int count, const double *__restrict__ l, const double *__restri
 // Lagrangian gradient v = g - (dc/dx)^T r for the next update.  State rows are addressed by problem, the
 // request's own arrays by position in the list.  The factor is staged in the team's triangle (W.E), updated
 // there, written back, and then turned in place into the QP's e.
+// A request with MPC_QP_FLAG_AUG (slsqp_core.h) is Kraft's augmented problem for an inconsistent linearisation: the
+// factor as it is, one more variable with the weight 100 * 10^k (k in the flags' bits 3..5); the step's extra entry
+// goes to the problem's multiplier row behind the m constraint multipliers, R[p][m] (a bound row's place, unused).
+// Such requests are rare and are served by an instance of their own (kAug: it takes ONLY them, the plain instance only
+// the others and answers an augmented one with MPC_QP_MODE_DEFERRED, raising *aug_seen): the plain instance's code,
+// registers and workspace layout stay what they are without the augmented problem (both in one kernel: +1.2 .. 1.8 %
+// on whole solves that never meet one).
 // kRows (device-resident solves, kernels_slsqp.hip): the request list and its length come from device memory
 // (`count` is then only an upper bound), and the request's box, last step, new step and mode are the problem's own
 // rows (lo, hi, s_in = s_out, mode indexed by problem instead of by position in the list; r_out unused: the
 // multipliers stay in R).
-template <bool kLds, bool kRows>
+template <bool kLds, bool kRows, bool kAug>
 __global__ void __launch_bounds__(mpck::kQpThreads, MPC_QP_WAVES)
 qp_step_kernel(int H, int count, int rows, const int32_t *__restrict__ index, const int32_t *__restrict__ count_dev,
                const int32_t *__restrict__ flags, const double *__restrict__ lo, const double *__restrict__ hi, const double *s_in,
                double *L, const double *__restrict__ G, const double *__restrict__ C, const double *__restrict__ NZ, double *R,
                double *V, double *s_out, double *__restrict__ r_out, int32_t *__restrict__ mode, int32_t *head, double *work,
-               int *iwork, size_t wd, size_t wi)
+               int *iwork, size_t wd, size_t wi, int32_t *aug_seen)
 {
     const int n = 6 * H, m = 12 * (H + 1), mg = m + 2 * n, nzc = 6 * H + 3 * H * (H + 1);
     const int ldl = (n + 1) * n / 2 + 1;
-    const lsqspmd::Work W = team_work<kLds>(work, iwork, wd, wi, n, m);
+    const lsqspmd::Work W = team_work<kLds>(work, iwork, wd, wi, n, m, kAug ? 1 : 0);
     const HipTeam<kLds> T;
     if (kRows) count = *count_dev;
     // kRows: the teams take requests from a shared queue (QPs differ a lot in cost: a fixed share per team would leave
@@ -126,6 +136,13 @@ qp_step_kernel(int H, int count, int rows, const int32_t *__restrict__ index, co
         double *l = L + p * ldl, *r = R + p * mg, *v = V + p * n;
         const double *g = G + p * n, *c = C + p * m, *nz = NZ + p * nzc;
         const int fl = flags[q];
+        if (kAug != ((fl & MPC_QP_FLAG_AUG) != 0)) {             // the other instance's request
+            if (!kAug && threadIdx.x == 0) {
+                mode[q] = MPC_QP_MODE_DEFERRED;
+                if (aug_seen) *aug_seen = 1;
+            }
+            continue;
+        }
         QP_MARK_START(T);
         if (fl & 1) {                                            // the factor of the identity
             PAR_FOR(T, e, 0, ldl - 1) W.E[e] = 0.0;
@@ -158,7 +175,18 @@ qp_step_kernel(int H, int count, int rows, const int32_t *__restrict__ index, co
         if (fl & 3) PAR_FOR(T, e, 0, ldl - 1) l[e] = W.E[e];
         T.sync();
         QP_MARK(T, 10);       // staging in (no update) / factor written back
-        const int md = lsqspmd::lsq(T, W, H, g, c, nz, lo + q * n, hi + q * n, s_out + q * n, r);
+        int md;
+        if constexpr (kAug) {
+            if (threadIdx.x == 0) {
+                double rho = 100.0;                              // Kraft's l(n3), ten times larger per failed attempt
+                for (int k = (fl >> 3) & 7; k > 0; --k) rho = 10.0 * rho;
+                W.E[ldl - 1] = rho;
+            }
+            T.sync();
+            md = lsqspmd::lsq<true>(T, W, H, g, c, nz, lo + q * n, hi + q * n, s_out + q * n, r, r + m);
+        } else {
+            md = lsqspmd::lsq(T, W, H, g, c, nz, lo + q * n, hi + q * n, s_out + q * n, r);
+        }
         T.sync();
         if (md == 1) {
             PAR_FOR(T, i, 0, n) {
@@ -188,10 +216,11 @@ namespace {
 #endif
 
 // LDS of one team, in bytes, when its small pool goes there (0: it stays in global memory).
-size_t lds_bytes(int H)
+size_t lds_bytes(int H, int aug = 0)
 {
     const int n = 6 * H, m = 12 * (H + 1);
-    const size_t b = lsqspmd::small_doubles(n, m, mpck::kQpThreads) * sizeof(double) + lsqspmd::work_ints(n, m, mpck::kQpThreads) * sizeof(int);
+    const size_t b = lsqspmd::small_doubles(n, m, mpck::kQpThreads, aug) * sizeof(double) +
+                     lsqspmd::work_ints(n, m, mpck::kQpThreads, aug) * sizeof(int);
     return b <= mpck::kQpLdsLimit ? b : 0;
 }
 
@@ -211,24 +240,24 @@ int qp_teams_per_cu(int H)
 }
 
 namespace {
-template <bool kRows>
+template <bool kRows, bool kAug>
 hipError_t launch_qp_step_any(int H, int count, int teams, int rows, const int32_t *index, const int32_t *count_dev,
                               const int32_t *flags, const double *lo, const double *hi, const double *s_in, double *L, const double *G,
                               const double *C, const double *NZ, double *R, double *V, double *s_out, double *r_out, int32_t *mode,
-                              int32_t *head, double *work, int *iwork, hipStream_t stream)
+                              int32_t *head, double *work, int *iwork, int32_t *aug_seen, hipStream_t stream)
 {
-    const size_t lds = lds_bytes(H);
+    const size_t lds = lds_bytes(H, kAug ? 1 : 0);
     if (lds) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(qp_step_kernel<true, kRows>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(qp_step_kernel<true, kRows, kAug>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL((qp_step_kernel<true, kRows>), dim3((unsigned)teams), dim3(kQpThreads), lds, stream, H, count, rows, index,
-                           count_dev, flags, lo, hi, s_in, L, G, C, NZ, R, V, s_out, r_out, mode, head, work, iwork, qp_work_doubles(H),
-                           qp_work_ints(H));
+        hipLaunchKernelGGL((qp_step_kernel<true, kRows, kAug>), dim3((unsigned)teams), dim3(kQpThreads), lds, stream, H, count, rows,
+                           index, count_dev, flags, lo, hi, s_in, L, G, C, NZ, R, V, s_out, r_out, mode, head, work, iwork,
+                           qp_work_doubles(H), qp_work_ints(H), aug_seen);
     } else {
-        hipLaunchKernelGGL((qp_step_kernel<false, kRows>), dim3((unsigned)teams), dim3(kQpThreads), 0, stream, H, count, rows, index,
-                           count_dev, flags, lo, hi, s_in, L, G, C, NZ, R, V, s_out, r_out, mode, head, work, iwork, qp_work_doubles(H),
-                           qp_work_ints(H));
+        hipLaunchKernelGGL((qp_step_kernel<false, kRows, kAug>), dim3((unsigned)teams), dim3(kQpThreads), 0, stream, H, count, rows,
+                           index, count_dev, flags, lo, hi, s_in, L, G, C, NZ, R, V, s_out, r_out, mode, head, work, iwork,
+                           qp_work_doubles(H), qp_work_ints(H), aug_seen);
     }
     return hipGetLastError();
 }
@@ -239,23 +268,28 @@ hipError_t launch_qp_step(int H, int count, int teams, int rows, const int32_t *
                           double *R, double *V, double *s_out, double *r_out, int32_t *mode, double *work, int *iwork,
                           hipStream_t stream)
 {
-    return launch_qp_step_any<false>(H, count, teams, rows, index, nullptr, flags, lo, hi, s_in, L, G, C, NZ, R, V, s_out, r_out, mode,
-                                     nullptr, work, iwork, stream);
+    return launch_qp_step_any<false, false>(H, count, teams, rows, index, nullptr, flags, lo, hi, s_in, L, G, C, NZ, R, V, s_out,
+                                            r_out, mode, nullptr, work, iwork, nullptr, stream);
 }
 
 hipError_t launch_qp_step_rows(int H, int teams, int rows, const RowList &list, const int32_t *flags, const double *lo,
                                const double *hi, double *S, double *L, const double *G, const double *C, const double *NZ,
-                               double *R, double *V, int32_t *mode, double *work, int *iwork, hipStream_t stream)
+                               double *R, double *V, int32_t *mode, double *work, int *iwork, int32_t *aug_seen, bool augmented,
+                               hipStream_t stream)
 {
     if (list.bound <= 0) return hipSuccess;
     if (list.head == nullptr) return hipErrorInvalidValue;
     const int t = teams < list.bound ? teams : list.bound;
-    return launch_qp_step_any<true>(H, list.bound, t, rows, list.list, list.count, flags, lo, hi, S, L, G, C, NZ, R, V, S, nullptr,
-                                    mode, list.head, work, iwork, stream);
+    if (augmented)
+        return launch_qp_step_any<true, true>(H, list.bound, t, rows, list.list, list.count, flags, lo, hi, S, L, G, C, NZ, R, V, S,
+                                              nullptr, mode, list.head, work, iwork, nullptr, stream);
+    return launch_qp_step_any<true, false>(H, list.bound, t, rows, list.list, list.count, flags, lo, hi, S, L, G, C, NZ, R, V, S,
+                                           nullptr, mode, list.head, work, iwork, aug_seen, stream);
 }
 
-size_t qp_work_doubles(int H) { return lsqspmd::work_doubles(6 * H, 12 * (H + 1), kQpThreads); }
-size_t qp_work_ints(int H) { return lsqspmd::work_ints(6 * H, 12 * (H + 1), kQpThreads); }
+// (sized for the augmented problem's layout, the larger of the two)
+size_t qp_work_doubles(int H) { return lsqspmd::work_doubles(6 * H, 12 * (H + 1), kQpThreads, 1); }
+size_t qp_work_ints(int H) { return lsqspmd::work_ints(6 * H, 12 * (H + 1), kQpThreads, 1); }
 
 hipError_t launch_qp(int H, int count, int teams, const double *l, const double *g, const double *c, const double *nz,
                      const double *lo, const double *hi, double *s, double *y, int32_t *mode, double *work, int *iwork,

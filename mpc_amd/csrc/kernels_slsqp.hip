@@ -198,7 +198,7 @@ __global__ void solve_begin_kernel(const mpc_params P, SolveWorkspace W, int cou
         W.QPMODE[p] = 0;
         W.QPFLAGS[p] = 0;
         slsqp_state z = {};
-        z.offload = 1;
+        z.offload = 2;                 // the QP kernel takes the augmented problem as well
         W.ST[p] = z;
     }
 }
@@ -213,13 +213,14 @@ __global__ void solve_begin_kernel(const mpc_params P, SolveWorkspace W, int cou
 // since round r - 1's body.
 // counters, per slot s at [8 s ..]: +0 f requests, +1 derivative requests, +2 QP requests, +3 their total (= problems
 // still unfinished, or -1 if a round met more requests than its grid was sized for; written by solve_count_kernel),
-// +4 the QP kernel's work-queue head; [kTotals ..] running totals of the three kinds over every round up to and
+// +4 the QP kernel's work-queue head, +5 that of its instance for augmented problems; [kTotals ..] running totals of the three kinds over every round up to and
 // including the old slot's (the first workgroup adds the old slot's lengths), [kOverflow] the sticky flag "a round's
 // `bound` was smaller than its lists".  One atomic per kind and workgroup (every problem of a lock-step round would
 // increment the same word, and L2 serialises them).
 constexpr int kBodyWaves = 4;      // problems per workgroup of solve_body_kernel, one wavefront each (fewer if LDS is short)
 
-__global__ __launch_bounds__(64 * kBodyWaves) void solve_body_kernel(int H, SolveWorkspace W, int old, int cs_old, int cs_new,
+// (three workgroups per CU is what their LDS allows at H = 20: the registers are held to that, 168 per lane)
+__global__ __launch_bounds__(64 * kBodyWaves, 3) void solve_body_kernel(int H, SolveWorkspace W, int old, int cs_old, int cs_new,
                                                                      int cs_next)
 {
     extern __shared__ double body_lds[];
@@ -239,12 +240,25 @@ __global__ __launch_bounds__(64 * kBodyWaves) void solve_body_kernel(int H, Solv
     if (k < cF) p = W.LIST_F[old][k];
     else if ((k -= cF) < cG) p = W.LIST_G[old][k];
     else if ((k -= cG) < cQ) p = W.LIST_Q[old][k];
+    p = __builtin_amdgcn_readfirstlane(p);   // one problem per wavefront: said so, its scalars then live in scalar registers
     const bool live = p >= 0;                // a wavefront beyond the lists only takes part in the barriers
     const size_t per = (size_t)(6 * n + 3 * m);
     double *x = body_lds + wave * per, *x0 = x + n, *s = x0 + n, *u = s + n, *v = u + n, *g = v + n, *c = g + n, *mu = c + m,
            *r = mu + m;
     const size_t pp = live ? (size_t)p : 0;
     double *gx = W.X + pp * n, *gx0 = W.X0 + pp * n, *gs = W.S + pp * n, *gmu = W.MU + pp * m;
+    // the problem's scalars are requested here, with the vectors, not after the barrier where they are used (a second
+    // and, for the QP's answer, a third trip to memory on a kernel that is little else than latency)
+    int mode = 0, iter = 0, qp_mode = 0;
+    double acc = 0.0, fval = 0.0, qp_delta = 0.0;
+    if (live) {
+        mode = W.MODE[p];
+        iter = W.ITER[p];
+        qp_mode = W.QPMODE[p];
+        acc = W.ACC[p];
+        fval = W.F[p];
+        qp_delta = W.RM[pp * mg + m];                               // an augmented problem's extra entry of the step
+    }
     if (live) {
         // every load of up to 256 entries of the seven vectors is issued before the first LDS store: one trip to
         // memory per pass (a single pass at H = 20) instead of one per vector and stride
@@ -272,29 +286,35 @@ __global__ __launch_bounds__(64 * kBodyWaves) void solve_body_kernel(int H, Solv
         }
     }
     __syncthreads();
+    bool box_fresh = false;                  // the body formed the QP's box in u, v (not so when it asks again, augmented)
     {
         // the whole wavefront runs the body (same scalars in every lane, the vectors shared out); its first lane files
         // the scalars away
         int kind = -1;
-        if (live) {
-            int mode = W.MODE[p];
+        // (a problem whose augmented QP met the plain QP kernel in a round without the augmented one - mpc_solve_rounds
+        //  launches that only once such a request has been seen - has not been served: it asks again, as it stands)
+        const bool deferred = live && mode == MPC_SLSQP_MODE_QP && qp_mode == MPC_QP_MODE_DEFERRED;
+        if (deferred) kind = 2;
+        if (live && !deferred) {
             slsqp_state S = W.ST[p];
-            if (mode == MPC_SLSQP_MODE_QP) S.qp_mode = W.QPMODE[p];
-            int iter = W.ITER[p];
-            double acc = W.ACC[p];
+            if (mode == MPC_SLSQP_MODE_QP) {
+                S.qp_mode = qp_mode;
+                S.qp_delta = qp_delta;
+            }
 #if defined(__HIP_DEVICE_COMPILE__)
-            slsqp_body_device(m, 0, m, n, x, W.lb, W.ub, W.F[p], c, g, nullptr, &acc, &iter, &mode, r, nullptr, x0, mu, s, u, v,
+            slsqp_body_device(m, 0, m, n, x, W.lb, W.ub, fval, c, g, nullptr, &acc, &iter, &mode, r, nullptr, x0, mu, s, u, v,
                               nullptr, nullptr, &S);
 #endif
             if (mode == 1) kind = 0;
             else if (mode == -1) kind = 1;
             else if (mode == MPC_SLSQP_MODE_QP) kind = 2;
+            box_fresh = kind == 2 && !S.qp_aug;
             if (lane == 0) {
                 W.ST[p] = S;
                 W.ITER[p] = iter;
                 W.ACC[p] = acc;
                 W.MODE[p] = mode;                                   // not 1, -1 or QP: finished, this is the exit mode
-                if (kind == 2) W.QPFLAGS[p] = (S.qp_reset ? 1 : 0) | (S.qp_bfgs ? 2 : 0);
+                if (kind == 2) W.QPFLAGS[p] = MPC_QP_FLAGS_OF(&S);
             }
         }
         if (lane == 0) ask[wave] = kind;
@@ -318,8 +338,10 @@ __global__ __launch_bounds__(64 * kBodyWaves) void solve_body_kernel(int H, Solv
     for (int i = lane; i < n; i += 64) { gx[i] = x[i]; gx0[i] = x0[i]; gs[i] = s[i]; }
     for (int i = lane; i < m; i += 64) gmu[i] = mu[i];
     if (kind == 2) {
-        double *gu = W.LO + pp * n, *gv = W.HI + pp * n;
-        for (int i = lane; i < n; i += 64) { gu[i] = u[i]; gv[i] = v[i]; }
+        if (box_fresh) {
+            double *gu = W.LO + pp * n, *gv = W.HI + pp * n;
+            for (int i = lane; i < n; i += 64) { gu[i] = u[i]; gv[i] = v[i]; }
+        }
     } else if (kind >= 0) {
         double *xe = W.XE + pp * n;                                 // the point to evaluate, inside the box (_clip_x_for_func)
         for (int i = lane; i < n; i += 64) {

@@ -73,64 +73,71 @@ struct SerialTeam {
 
 #define PAR_FOR(T, i, lo, hi) for (int i = (lo) + (T).tid(); i < (hi); i += (T).size())
 
-// Workspace of one team (doubles unless noted), sized for Kraft's augmented problem (one variable more: n + 1
-// variables, two more bound rows): mga = m + 2n + 2 rows of [g h], n2 = n + 2 columns (the variables and h).  The
-// plain problem uses mg = m + 2n and n + 1 of them.  Two pools: the BIG one holds the two
+// Workspace of one team (doubles unless noted).  mg = m + 2n rows of [g h] and n1 = n + 1 columns (the variables
+// and h) for the plain problem; Kraft's augmented problem (aug = 1: one variable more, two more bound rows) has
+// mg + 2 and n + 2, and every size below is taken with those.  Two pools: the BIG one holds the two
 // matrices and lives in global memory; the SMALL one (the packed triangle and every vector) is what the serial
 // sections and the broadcast reads touch, and goes to LDS when it fits (kernels_qp.hip).
+// (The plain problem keeps its own, smaller layout: carved with the augmented sizes, whole solves were 1 % slower.)
 struct Work {
-    double *G;     // [n2*mga]: G[i + j*ld] = g(i, j) for j < N; G[i + N*ld] = h(i)  (N variables, ld rows: n, mg or n + 1, mga)
-    double *AT;    // [n2*mga]: the copy NNLS works on and overwrites (LDP needs g and h again afterwards)
+    double *G;     // [n1*mg]: G[i + j*mg] = g(i, j) for j < n; G[i + n*mg] = h(i)
+    double *AT;    // [n1*mg]: the copy NNLS works on and overwrites (LDP needs g and h again afterwards)
     double *E;     // [n(n+1)/2 + 1]: on entry the packed LDL' factor l; lsq turns it IN PLACE into e = sqrt(d) l^T,
                    // e(r, c) for r <= c at E[off(r) + c - r], off(r) = r n - r(r-1)/2 (0-based), i.e. row by row;
                    // the last entry is the augmented problem's e(n, n) = rho (Kraft's l(n3)), unused otherwise
     double *ff;    // [n]
-    double *acc;   // [max(mga, team size)]; NNLS's reduction (redv) borrows it
-    double *bb;    // [n2]  NNLS right-hand side
-    double *zz;    // [n2]
-    double *xn;    // [mga]  NNLS solution (dual variables of LDP)
-    double *wd;    // [mga]  NNLS dual vector
-    double *piv;   // [n2]  copy of the pivot column
-    double *xs;    // [n + 1]
+    double *acc;   // [max(mg, team size)]; NNLS's reduction (redv) borrows it
+    double *bb;    // [n1]  NNLS right-hand side
+    double *zz;    // [n1]
+    double *xn;    // [mg]  NNLS solution (dual variables of LDP)
+    double *wd;    // [mg]  NNLS dual vector
+    double *piv;   // [n1]  copy of the pivot column
+    double *xs;    // [n + aug]
     double *sc;    // [16]  scalars broadcast from thread 0
     double *redv;  // = acc
-    int *redi;     // [max(team size, n2)]: NNLS's reduction; afterwards the final set, sorted
-    int *idx;      // [mga]
+    int *redi;     // [max(team size, n1)]: NNLS's reduction; afterwards the final set, sorted
+    int *idx;      // [mg]
     int *isc;      // [16]
 };
 
-SPMD_HD inline size_t big_doubles(int n, int m) { return 2 * ((size_t)n + 2) * ((size_t)m + 2 * (size_t)n + 2); }
-SPMD_HD inline size_t small_doubles(int n, int m, int team)
+SPMD_HD inline size_t big_doubles(int n, int m, int aug = 0)
 {
-    const size_t mga = (size_t)m + 2 * (size_t)n + 2, n2 = (size_t)n + 2;
-    const size_t accn = mga > (size_t)team ? mga : (size_t)team;
-    return (size_t)n * (n + 1) / 2 + 1 + n + accn + n2 + n2 + mga + mga + n2 + (n + 1) + 16;
+    return 2 * ((size_t)n + 1 + aug) * ((size_t)m + 2 * (size_t)n + 2 * aug);
 }
-SPMD_HD inline size_t work_doubles(int n, int m, int team) { return big_doubles(n, m) + small_doubles(n, m, team); }
-SPMD_HD inline size_t work_ints(int n, int m, int team)
+SPMD_HD inline size_t small_doubles(int n, int m, int team, int aug = 0)
 {
-    return (size_t)(team > n + 2 ? team : n + 2) + (size_t)m + 2 * (size_t)n + 2 + 16;
+    const size_t mg = (size_t)m + 2 * (size_t)n + 2 * aug, n1 = (size_t)n + 1 + aug;
+    const size_t accn = mg > (size_t)team ? mg : (size_t)team;
+    return (size_t)n * (n + 1) / 2 + 1 + n + accn + n1 + n1 + mg + mg + n1 + (n + aug) + 16;
+}
+SPMD_HD inline size_t work_doubles(int n, int m, int team, int aug = 0)
+{
+    return big_doubles(n, m, aug) + small_doubles(n, m, team, aug);
+}
+SPMD_HD inline size_t work_ints(int n, int m, int team, int aug = 0)
+{
+    return (size_t)(team > n + 1 + aug ? team : n + 1 + aug) + (size_t)m + 2 * (size_t)n + 2 * aug + 16;
 }
 
-SPMD_HD inline Work carve(double *big, double *d, int *i, int n, int m, int team)
+SPMD_HD inline Work carve(double *big, double *d, int *i, int n, int m, int team, int aug = 0)
 {
-    const size_t mga = (size_t)m + 2 * (size_t)n + 2, n2 = (size_t)n + 2;
+    const size_t mg = (size_t)m + 2 * (size_t)n + 2 * aug, n1 = (size_t)n + 1 + aug;
     Work W;
     W.G = big;
-    W.AT = big + n2 * mga;
+    W.AT = big + n1 * mg;
     W.E = d;            d += (size_t)n * (n + 1) / 2 + 1;
     W.ff = d;           d += n;
-    W.acc = d;          d += mga > (size_t)team ? mga : (size_t)team;
-    W.bb = d;           d += n2;
-    W.zz = d;           d += n2;
-    W.xn = d;           d += mga;
-    W.wd = d;           d += mga;
-    W.piv = d;          d += n2;
-    W.xs = d;           d += n + 1;
+    W.acc = d;          d += mg > (size_t)team ? mg : (size_t)team;
+    W.bb = d;           d += n1;
+    W.zz = d;           d += n1;
+    W.xn = d;           d += mg;
+    W.wd = d;           d += mg;
+    W.piv = d;          d += n1;
+    W.xs = d;           d += n + aug;
     W.sc = d;
     W.redv = W.acc;
-    W.redi = i;         i += team > n + 2 ? team : n + 2;
-    W.idx = i;          i += mga;
+    W.redi = i;         i += (size_t)team > n1 ? (size_t)team : n1;
+    W.idx = i;          i += mg;
     W.isc = i;
     return W;
 }
@@ -1137,7 +1144,7 @@ __device__ __attribute__((noinline)) void transform_rows_call(const double *E, c
 // mode 4; slsqp_core.c's lsq with n2 = 1): one more variable delta in [0, 1] with the column max(-c, 0) in the
 // constraint rows and the weight rho = W.E[n(n+1)/2] (Kraft's l(n3)) as its row of e.  N = n + 1 variables, two more
 // bound rows (delta's lower bound follows the other lower bounds, its upper bound the other upper bounds), the rows
-// of [g h] ld = mg + 2 apart; *delta receives the last entry of the step.  What the extra row and column of e
+// of [g h]; *delta receives the last entry of the step.  What the extra row and column of e
 // contribute to the sums of the other variables are products with exact zeros at the end of sums that are never
 // -0.0 (delta finite): those terms are left out, every other operation is the serial text's.
 template <bool AUG = false, class Team>
@@ -1146,7 +1153,7 @@ SPMD_HD int lsq(const Team &T, const Work &W, int H, const double *g, const doub
 {
     static_assert(!AUG || MPC_QP_ROWS == 1, "the augmented transform is written for one row per lane");
     const int n = 6 * H, m = 12 * (H + 1), mg = m + 2 * n;
-    const int N = n + (AUG ? 1 : 0), ld = mg + (AUG ? 2 : 0);
+    const int N = n + (AUG ? 1 : 0), ld = mg + (AUG ? 2 : 0);           // ld rows of [g h], columns ld apart
 #define EO(r) ((r) * n - ((r) * ((r) - 1)) / 2)
     QP_MARK_START(T);
     // ---- e = sqrt(d) l^T in place (row r of e is column r of l scaled by sqrt(d_r))

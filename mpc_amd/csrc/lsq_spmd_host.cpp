@@ -30,8 +30,8 @@ extern "C" void mpc_lsq_spmd_serial(int m, int meq, int n, int nl, int la, doubl
         return;
     }
     const int nzc = 6 * H + 3 * H * (H + 1), mg = m + 2 * nv;
-    std::vector<double> nz(nzc), dw(lsqspmd::work_doubles(nv, m, 1)), yy(mg);
-    std::vector<int> iw(lsqspmd::work_ints(nv, m, 1));
+    std::vector<double> nz(nzc), dw(lsqspmd::work_doubles(nv, m, 1, aug ? 1 : 0)), yy(mg);
+    std::vector<int> iw(lsqspmd::work_ints(nv, m, 1, aug ? 1 : 0));
     for (int j = 0; j < H; ++j) {
         const int tri = j * H - (j * (j - 1)) / 2 - j - 1;
         for (int q = 0; q < 6; ++q) {
@@ -40,7 +40,7 @@ extern "C" void mpc_lsq_spmd_serial(int m, int meq, int n, int nl, int la, doubl
             for (int k = j + 1; k <= H; ++k) nz[6 * H + 6 * (tri + k) + q] = a[(12 * k + q) + (size_t)col * la];
         }
     }
-    lsqspmd::Work W = lsqspmd::carve(dw.data(), dw.data() + lsqspmd::big_doubles(nv, m), iw.data(), nv, m, 1);
+    lsqspmd::Work W = lsqspmd::carve(dw.data(), dw.data() + lsqspmd::big_doubles(nv, m, aug ? 1 : 0), iw.data(), nv, m, 1, aug ? 1 : 0);
     for (int e = 0; e < nl; ++e) W.E[e] = l[e];                  // lsq works on its own copy of the factor
     if (aug) {
         mpc_lsq_spmd_augmented_calls++;
@@ -76,4 +76,42 @@ extern "C" void mpc_bfgs_spmd_serial(int m, int n, int la, double *l, double *g,
     }
     lsqspmd::Work W = lsqspmd::carve(dw.data(), dw.data() + lsqspmd::big_doubles(n, m), iw.data(), n, m, 1);
     lsqspmd::bfgs_update(lsqspmd::SerialTeam(), W, H, l, g, nz.data(), r, v, s, u);
+}
+
+// One request of mpc_qp_step (kernels_qp.hip: qp_step_kernel) for one problem, with a team of one on the host: reset
+// or BFGS-update the factor l, solve the QP (plain or augmented, see the flags in slsqp_core.h), keep the multipliers
+// in r [m + 2n + 2] and the Lagrangian gradient in v.  Tests drive the QP-offload protocol of slsqp_body.inc with it
+// where there is no GPU.  lo / hi / s: the request's box and the last step (in), the new step (out, if the mode is 1).
+extern "C" int mpc_qp_step_serial(int H, int flags, const double *lo, const double *hi, double *s, double *l, const double *g,
+                                  const double *c, const double *nz, double *r, double *v)
+{
+    const int n = 6 * H, m = 12 * (H + 1), ldl = (n + 1) * n / 2 + 1, aug = (flags & MPC_QP_FLAG_AUG) ? 1 : 0;
+    std::vector<double> dw(lsqspmd::work_doubles(n, m, 1, aug)), s_in(s, s + n);
+    std::vector<int> iw(lsqspmd::work_ints(n, m, 1, aug));
+    const lsqspmd::SerialTeam T;
+    lsqspmd::Work W = lsqspmd::carve(dw.data(), dw.data() + lsqspmd::big_doubles(n, m, aug), iw.data(), n, m, 1, aug);
+    if (flags & MPC_QP_FLAG_RESET) {
+        for (int e = 0; e < ldl - 1; ++e) W.E[e] = 0.0;
+        for (int i = 0; i < n; ++i) W.E[i * n - (i * (i - 1)) / 2] = 1.0;
+    } else {
+        for (int e = 0; e < ldl - 1; ++e) W.E[e] = l[e];
+    }
+    if (flags & MPC_QP_FLAG_BFGS) {
+        for (int i = 0; i < n; ++i) { W.bb[i] = v[i]; W.zz[i] = s_in[i]; }
+        lsqspmd::bfgs_update(T, W, H, W.E, g, nz, r, W.bb, W.zz, W.xs);
+    }
+    if (flags & (MPC_QP_FLAG_RESET | MPC_QP_FLAG_BFGS))
+        for (int e = 0; e < ldl - 1; ++e) l[e] = W.E[e];
+    int md;
+    if (flags & MPC_QP_FLAG_AUG) {
+        double rho = 100.0;
+        for (int k = (flags >> 3) & 7; k > 0; --k) rho = 10.0 * rho;
+        W.E[ldl - 1] = rho;
+        md = lsqspmd::lsq<true>(T, W, H, g, c, nz, lo, hi, s, r, r + m);
+    } else {
+        md = lsqspmd::lsq(T, W, H, g, c, nz, lo, hi, s, r);
+    }
+    if (md == 1)
+        for (int i = 0; i < n; ++i) v[i] = g[i] - lsqspmd::jac_column_dot(H, nz, r, i);
+    return md;
 }

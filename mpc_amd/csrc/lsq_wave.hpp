@@ -106,7 +106,9 @@ __device__ __forceinline__ double ordered_sum_from(double t, const double (&p)[8
     const double one = 1.0;
     // the jump lands (s_getpc_b64 gives the address of the instruction after it) 12 bytes of scalar instructions
     // plus 8 bytes per skipped term further on; first == 128 skips them all
-    const int off = 12 + 8 * first;
+    // (first is the same in every lane; said explicitly, because where the compiler cannot prove it - inside a function
+    //  that is not inlined, whose arguments arrive in vector registers - the "s" operand below would be handed one)
+    const int off = 12 + 8 * __builtin_amdgcn_readfirstlane(first);
     asm volatile("s_nop 1\n\t"                       // a VALU result (p) may not be read through DPP in the next two slots
                  "s_getpc_b64 s[38:39]\n"
                  ".Llsqw_pc%=:\n\t"

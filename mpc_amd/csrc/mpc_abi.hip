@@ -26,6 +26,7 @@ struct mpc_ctx {
     double *d_qp_work = nullptr;  // mpc_qp_solve: workspace of the resident workgroups (allocated on first use)
     int *d_qp_iwork = nullptr;
     int qp_teams = 0;
+    int32_t *aug_seen = nullptr;      // pinned host memory the device writes: a resident solve met an augmented QP request
     const void *solve_ws = nullptr;   // mpc_solve_*: the workspace mpc_solve_begin set up, and how many rounds have run on
     int solve_round = 0;              // it: round r's requests are in list buffer (r + 1) % 2, counter slot (r + 1) % 3
     double *d_static = nullptr;   // this device's copy of the file-scope `scratch` array (mpc_eval_fd_static)
@@ -163,6 +164,7 @@ void mpc_ctx_destroy(mpc_ctx *ctx)
     if (ctx->d_decay) (void)hipFree(ctx->d_decay);
     if (ctx->d_fvals) (void)hipFree(ctx->d_fvals);
     if (ctx->d_work) (void)hipFree(ctx->d_work);
+    if (ctx->aug_seen) (void)hipHostFree(ctx->aug_seen);
     if (ctx->d_qp_work) (void)hipFree(ctx->d_qp_work);
     if (ctx->d_qp_iwork) (void)hipFree(ctx->d_qp_iwork);
     for (int h = 0; h < 2; ++h) {
@@ -543,6 +545,12 @@ int mpc_solve_begin(mpc_ctx *ctx, const mpc_scenarios *sc, const double *x0, dou
     MPC_HIP(ctx, mpck::launch_solve_begin(ctx->params, W, sc->count, x0, acc, maxiter, st));
     // mode 0 on entry: f, c, grad f and dc/dx at the (clipped) start point for everyone (SLSQP:419-425)
     MPC_HIP(ctx, mpck::launch_prefix_nz(ctx->params, ctx->d_decay, *sc, W.XE, W.F, W.G, W.C, W.NZ, st));
+    if (!ctx->aug_seen) {
+        // one word of host memory the QP kernel raises when it meets Kraft's augmented problem (rare: an inconsistent
+        // linearisation); from the next mpc_solve_rounds call on, the rounds also launch the kernel that solves those
+        MPC_HIP(ctx, hipHostMalloc(reinterpret_cast<void **>(&ctx->aug_seen), sizeof(int32_t), hipHostMallocMapped));
+    }
+    *ctx->aug_seen = 0;
     ctx->solve_ws = ws;
     ctx->solve_round = 0;
     return MPC_OK;
@@ -574,6 +582,9 @@ int mpc_solve_rounds(mpc_ctx *ctx, const mpc_scenarios *sc, void *ws, int rows, 
             return hip_fail(ctx, e_, #call);                     \
         }                                                        \
     } while (0)
+    // has any round so far met an augmented QP request?  (Read without synchronisation: the word only ever goes from 0
+    // to 1 during a solve, and a request that meets a round without the augmented kernel simply asks again.)
+    const bool augmented = *static_cast<volatile int32_t *>(ctx->aug_seen) != 0;
     for (int r = 0; r < rounds && bound > 0; ++r) {     // bound == 0: nothing is unfinished, the state stays as it is
         const int round = ctx->solve_round, cur = (round + 1) & 1, cs = (round + 1) % 3;
         MPC_SOLVE_HIP(mpck::launch_solve_body(ctx->horizon, W, bound, round, st));
@@ -589,7 +600,13 @@ int mpc_solve_rounds(mpc_ctx *ctx, const mpc_scenarios *sc, void *ws, int rows, 
         MPC_SOLVE_HIP(mpck::launch_prefix_rows(ctx->params, ctx->d_decay, *sc, W.XE, W.F, W.G, nullptr, W.NZ, lg, st));
         // BFGS update + QP of the problems that start a major iteration
         MPC_SOLVE_HIP(mpck::launch_qp_step_rows(ctx->horizon, ctx->qp_teams, rows, lq, W.QPFLAGS, W.LO, W.HI, W.S, W.L, W.G, W.C,
-                                                W.NZ, W.RM, W.V, W.QPMODE, ctx->d_qp_work, ctx->d_qp_iwork, st));
+                                                W.NZ, W.RM, W.V, W.QPMODE, ctx->d_qp_work, ctx->d_qp_iwork, ctx->aug_seen, false, st));
+        if (augmented) {                                    // ... and Kraft's augmented problems, where there are any
+            lq.head = W.counters + 8 * cs + 5;
+            MPC_SOLVE_HIP(mpck::launch_qp_step_rows(ctx->horizon, ctx->qp_teams, rows, lq, W.QPFLAGS, W.LO, W.HI, W.S, W.L, W.G,
+                                                    W.C, W.NZ, W.RM, W.V, W.QPMODE, ctx->d_qp_work, ctx->d_qp_iwork, nullptr, true,
+                                                    st));
+        }
     }
     const int slot = ctx->solve_round % 3;
     MPC_SOLVE_HIP(mpck::launch_solve_count(W, slot, st));

@@ -69,6 +69,7 @@ hipError_t launch_qp(int H, int count, int teams, const double *l, const double 
                      hipStream_t stream);
 
 #define MPC_QP_MODE_BAD_INDEX (-100)   // mpc_qp_step: the request's problem index lies outside [0, rows)
+#define MPC_QP_MODE_DEFERRED (-101)    // an augmented request (MPC_QP_FLAG_AUG) met the plain instance: not served yet
 hipError_t launch_qp_step(int H, int count, int teams, int rows, const int32_t *index, const int32_t *flags, const double *lo,
                           const double *hi, const double *s_in, double *L, const double *G, const double *C, const double *NZ,
                           double *R, double *V, double *s_out, double *r_out, int32_t *mode, double *work, int *iwork,
@@ -105,12 +106,15 @@ struct RowList {
     int bound = 0;
     int32_t *head = nullptr;          // device, zero on entry: work-queue head of the QP kernel (teams take requests in turn)
 };
+// augmented = false: the plain instance (augmented requests are answered MPC_QP_MODE_DEFERRED and *aug_seen, which may
+// be host memory the device can write, is set to 1); true: the instance that serves only the augmented requests.
 hipError_t launch_sincos_probe(int n, const double *x, double *sn, double *cs, hipStream_t stream);
 hipError_t launch_prefix_rows(const mpc_params &P, const double *decay, const mpc_scenarios &sc, const double *x, double *cost,
                               double *grad, double *con, double *nz, const RowList &rows, hipStream_t stream);
 hipError_t launch_qp_step_rows(int H, int teams, int rows, const RowList &list, const int32_t *flags, const double *lo,
                                const double *hi, double *S, double *L, const double *G, const double *C, const double *NZ,
-                               double *R, double *V, int32_t *mode, double *work, int *iwork, hipStream_t stream);
+                               double *R, double *V, int32_t *mode, double *work, int *iwork, int32_t *aug_seen, bool augmented,
+                               hipStream_t stream);
 
 // dst row i = src row index[i] for every scenario array (NaN rows for an index outside [0, src.count))
 hipError_t launch_gather_scenarios(int H, const mpc_scenarios &src, const int32_t *index, int count,

@@ -125,7 +125,7 @@ const int32_t *mpc_slsqp_iterations(mpc_slsqp_batch *b) { return b->iter; }
 int mpc_slsqp_set_offload(mpc_slsqp_batch *b, int on)
 {
     if (!b) return -1;
-    b->offload = on ? 1 : 0;
+    b->offload = on < 0 ? 0 : (on > 2 ? 2 : on);      /* 2: the caller solves the augmented problem as well (slsqp_core.h) */
     return 0;
 }
 double *mpc_slsqp_lo(mpc_slsqp_batch *b) { return b->u; }
@@ -157,7 +157,10 @@ int mpc_slsqp_advance_qp(mpc_slsqp_batch *b, int32_t *want_f, int32_t *n_want_f,
         double *a = b->ascr + (size_t)tid * n1 * m;
         double *g = b->g + (size_t)p * n1;
         if (b->offload) {
-            if (b->mode[p] == MPC_SLSQP_MODE_QP) b->st[p].qp_mode = b->qpmode[p];
+            if (b->mode[p] == MPC_SLSQP_MODE_QP) {
+                b->st[p].qp_mode = b->qpmode[p];
+                b->st[p].qp_delta = b->r[(size_t)p * b->r_len + m];      /* an augmented problem's extra entry */
+            }
             if (b->mode[p] != 1) g[n] = 0.0;
         } else if (b->mode[p] != 1) {
             /* fresh derivatives: the dense a(m, n+1) of this call, zero except the structured entries.  A call
@@ -174,7 +177,7 @@ int mpc_slsqp_advance_qp(mpc_slsqp_batch *b, int32_t *want_f, int32_t *n_want_f,
                    b->jwscr + (size_t)tid * b->ljw, &b->st[p]);
         b->mode[p] = mode;
         b->iter[p] = iter;
-        b->qpflags[p] = (b->st[p].qp_reset ? 1 : 0) | (b->st[p].qp_bfgs ? 2 : 0);
+        b->qpflags[p] = MPC_QP_FLAGS_OF(&b->st[p]);
         if (mode != 1 && mode != -1 && mode != MPC_SLSQP_MODE_QP) b->done[p] = 1;
         b->tsec[tid] += omp_get_wtime() - t0;
     }

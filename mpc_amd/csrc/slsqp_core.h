@@ -14,14 +14,27 @@ typedef struct slsqp_state {
      * it would reset l it sets qp_reset, where it would update l (BFGS) it sets qp_bfgs, and where it would solve
      * the QP it returns MPC_SLSQP_MODE_QP with u = xl - x and v = xu - x in place.  The caller resets / updates l,
      * solves the QP (mpc_qp_step in include/mpc_amd.h does all three on the device), writes the step into s, the
-     * constraint multipliers into r, the QP's mode into qp_mode, and calls again with mode = MPC_SLSQP_MODE_QP. */
+     * constraint multipliers into r, the QP's mode into qp_mode, and calls again with mode = MPC_SLSQP_MODE_QP.
+     * offload = 2: the caller also solves Kraft's augmented problem (inconsistent linearisation, QP mode 4): the body
+     * asks again with qp_aug set (no reset, no update; the weight of the extra variable is 100 * 10^incons, Kraft's
+     * l(n3)), the caller answers with the step's extra entry in qp_delta as well, up to six times with ten times the
+     * weight.  offload = 1: such a solve ends with MPC_SLSQP_MODE_NEEDS_HOST. */
     int offload, qp_mode, qp_reset, qp_bfgs;
+    int qp_aug, qp_unused;
+    double qp_delta;
 } slsqp_state;
 
 #define MPC_SLSQP_MODE_QP 20
-/* exit mode of an offloaded solve whose linearisation was inconsistent (Kraft's augmented problem needs l on the
- * host): the caller solves that problem again with the host-only driver */
+/* exit mode of a solve offloaded to a caller that does not take Kraft's augmented problem (offload = 1) whose
+ * linearisation was inconsistent: the caller solves that problem again with the host-only driver */
 #define MPC_SLSQP_MODE_NEEDS_HOST 104
+/* the QP request's flags (mpc_qp_step): reset l / BFGS-update l / the augmented problem, its weight 100 * 10^k in
+ * bits 3..5 */
+#define MPC_QP_FLAG_RESET 1
+#define MPC_QP_FLAG_BFGS 2
+#define MPC_QP_FLAG_AUG 4
+#define MPC_QP_FLAGS_OF(S) (((S)->qp_reset ? MPC_QP_FLAG_RESET : 0) | ((S)->qp_bfgs ? MPC_QP_FLAG_BFGS : 0) | \
+                            ((S)->qp_aug ? (MPC_QP_FLAG_AUG | (((S)->incons & 7) << 3)) : 0))
 
 /* Body of the method with its persistent vectors passed one by one: r [m + 2n + 2] multipliers,
  * l [(n+1)n/2 + 1] LDL' factor of the BFGS matrix, x0 [n], mu [m], s / u / v [n+1], and per-call

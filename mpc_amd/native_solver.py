@@ -78,7 +78,9 @@ def load():
 class NativeBatch:
     """ctypes view of one ``mpc_slsqp_batch``: the rows as numpy arrays over the library's memory."""
 
-    def __init__(self, horizon: int, capacity: int, threads: int = 0, offload_qp: bool = False):
+    def __init__(self, horizon: int, capacity: int, threads: int = 0, offload_qp=False):
+        """offload_qp: False (the whole method on the host), True (the QP is the caller's; an inconsistent linearisation
+        ends the solve with MODE_NEEDS_HOST) or 2 (the caller solves Kraft's augmented problem as well, slsqp_core.h)."""
         self._lib = load()
         self._b = C.c_void_p()
         rc = self._lib.mpc_slsqp_create(horizon, capacity, threads, C.byref(self._b))
@@ -102,7 +104,7 @@ class NativeBatch:
         self._wq = np.zeros(capacity, dtype=np.int32)
         self.offload_qp = bool(offload_qp)
         if self.offload_qp:
-            self._lib.mpc_slsqp_set_offload(self._b, 1)
+            self._lib.mpc_slsqp_set_offload(self._b, 2 if offload_qp == 2 else 1)
             self.LO = view(L.mpc_slsqp_lo, (capacity, self.n + 1))
             self.HI = view(L.mpc_slsqp_hi, (capacity, self.n + 1))
             self.S = view(L.mpc_slsqp_s, (capacity, self.n + 1))

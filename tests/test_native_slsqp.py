@@ -161,6 +161,93 @@ def test_team_parallel_lsq_with_a_team_of_one_keeps_whole_solves_identical(H, N,
     np.testing.assert_array_equal(got[2], want[2])
 
 
+@pytest.mark.parametrize("H,N,bad", [(3, 8, (2, 5)), (20, 3, (1,)), (1, 6, (0, 3))])
+def test_offload_protocol_with_the_augmented_problem_keeps_whole_solves_identical(H, N, bad):
+    """The QP-offload form of the body (slsqp_body.inc with S->offload = 2, the form the device-resident solve runs)
+    against the whole method on the host, call by call: the body asks for its QPs, a team of one serves them through
+    mpc_qp_step_serial (the text of the device's qp_step_kernel: reset / BFGS update of the factor, the QP, the
+    multipliers and the Lagrangian gradient kept with the factor), and where a linearisation is inconsistent the body
+    asks for Kraft's augmented problem, up to six times with growing weight.  Same modes and iterates in every round
+    that both forms have (the offloaded one has the QP rounds in between), same exit."""
+    import ctypes as C
+
+    from mpc_amd import native_solver
+
+    lib = native_solver.load()
+    mp = params_for(H)
+    co, hs = host_scenarios(mp, N, motion="angular", cfg_id=43, goal_jitter=0.0 if H == 20 else 0.05)
+    hs.state0[list(bad), 0] = mp.q_limit + 0.2
+    n, m = mp.n, mp.m
+    lb = np.array([b[0] for b in mp.bounds()])
+    ub = np.array([b[1] for b in mp.bounds()])
+    scatter = nz_scatter_index(H)
+    dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+    lib.mpc_qp_step_serial.restype = C.c_int
+    lib.mpc_qp_step_serial.argtypes = [C.c_int, C.c_int] + [C.POINTER(C.c_double)] * 9
+
+    def solve(offload):
+        b = NativeBatch(H, N, threads=1, offload_qp=offload)
+        b.begin(np.tile(hs.u_init, (1, H)), lb, ub, mp.ftol, mp.maxiter)
+        f, g, c, a = co.eval_fd(_rows(hs, np.arange(N), b.X[:N]))
+        b.F[:N], b.Cc[:N], b.G[:N, :n], b.NZ[:N] = f, c, g, a.reshape(N, -1)[:, scatter]
+        L = np.zeros((N, (n + 1) * n // 2 + 1))
+        V = np.zeros((N, n))
+        trace, flags_seen = [], set()
+        while True:
+            if offload:
+                wf, wg, wq = (w.copy() for w in b.advance_qp())
+            else:
+                wf, wg = (w.copy() for w in b.advance())
+                wq = np.zeros(0, np.int32)
+            trace.append((b.X[:N].copy(), b.mode[:N].copy()))
+            if len(wf) + len(wg) + len(wq) == 0:
+                break
+            if len(wf):
+                f, c = co.eval(_rows(hs, wf, np.clip(b.X[wf], lb, ub)))
+                b.F[wf], b.Cc[wf] = f, c
+            if len(wg):
+                _, g, _, a = co.eval_fd(_rows(hs, wg, np.clip(b.X[wg], lb, ub)))
+                b.G[wg, :n] = g
+                b.NZ[wg] = a.reshape(len(wg), -1)[:, scatter]
+            for p in wq:
+                fl = int(b.QPFLAGS[p])
+                flags_seen.add(fl)
+                lo, hi, s = (np.ascontiguousarray(v[p, :n]) for v in (b.LO, b.HI, b.S))
+                g = np.ascontiguousarray(b.G[p, :n])
+                md = lib.mpc_qp_step_serial(H, fl, dp(lo), dp(hi), dp(s), dp(L[p]), dp(g), dp(b.Cc[p]), dp(b.NZ[p]), dp(b.R[p]),
+                                            dp(V[p]))
+                b.QPMODE[p] = md
+                if md == 1:
+                    b.S[p, :n] = s
+        out = (trace, b.iterations[:N].copy(), b.F[:N].copy(), flags_seen)
+        b.close()
+        return out
+
+    want = solve(False)
+    got = solve(2)
+    assert any(fl & 4 for fl in got[3]), "no augmented problem was met"
+    # the offloaded form's rounds that ask for a QP are extra; in every other round both forms stand at the same point
+    QP = 20
+    mine = [(x, md) for x, md in got[0]]
+    k = np.zeros(N, int)                                   # per problem: position in the host form's trace
+    host_modes = np.stack([md for _, md in want[0]])
+    host_x = np.stack([x for x, _ in want[0]])
+    done = np.zeros(N, bool)
+    for x, md in mine:
+        for i in range(N):
+            if done[i] or md[i] == QP:
+                continue
+            assert md[i] == host_modes[k[i], i]
+            np.testing.assert_array_equal(x[i], host_x[k[i], i])
+            if md[i] not in (1, -1):
+                done[i] = True
+            else:
+                k[i] += 1
+    assert done.all()
+    np.testing.assert_array_equal(got[1], want[1])
+    np.testing.assert_array_equal(got[2], want[2])
+
+
 def test_offload_staging_packs_and_unpacks_rows():
     """mpc_slsqp_pack / mpc_slsqp_unpack (QP offload): one round's requests gathered into / scattered from flat
     staging buffers with the layouts include/mpc_slsqp.h gives."""
