@@ -36,7 +36,7 @@ def qp_roofline(dst, spec):
     qp = [r for r in rows if "qp_step_kernel" in r["Name"]]
     occ = (c["SQ_THREAD_CYCLES_VALU"] / (64.0 * c["SQ_ACTIVE_INST_VALU"])
            if "SQ_THREAD_CYCLES_VALU" in c and c.get("SQ_ACTIVE_INST_VALU") else None)
-    out = {"kernel": "qp_step_kernel<true, true>", "horizon": int(H), "qps_per_counter_launch": K,
+    out = {"kernel": "qp_step_kernel<true, true, false>", "horizon": int(H), "qps_per_counter_launch": K,
            "wave_instructions_per_launch": {k[14:]: c[k] for k in c if k.startswith("SQ_INSTS_VALU_") and k.endswith("F64")},
            "executed_flops_per_qp": flops / K, "lane_occupancy": occ,
            "FETCH_SIZE_KiB": c["FETCH_SIZE"], "WRITE_SIZE_KiB": c["WRITE_SIZE"], "fetch_correction": 2.0,
