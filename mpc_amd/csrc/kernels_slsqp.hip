@@ -251,6 +251,7 @@ __global__ __launch_bounds__(64 * kBodyWaves, 3) void solve_body_kernel(int H, S
     // and, for the QP's answer, a third trip to memory on a kernel that is little else than latency)
     int mode = 0, iter = 0, qp_mode = 0;
     double acc = 0.0, fval = 0.0, qp_delta = 0.0;
+    (void)fval;                              // (read in the device pass only)
     if (live) {
         mode = W.MODE[p];
         iter = W.ITER[p];
