@@ -402,7 +402,9 @@ def solve_rate(ctx, mp, sample, threads, rank, world, dist, driver="resident", s
             native = (DeviceQpSLSQP if driver == "device_qp" else NativeBatchedSLSQP)(ctx, threads=threads, capacity=count)
         log("solver up")
         warm = min(count, 32)
-        BatchedMPC(ctx, solver=native).compute_control(hs.q0[:warm], hs.state0[:warm, 12:18], hs.target[:warm], hs.base[:warm])
+        prep = "resident" if driver == "resident" else "host"    # resident: start points and solutions never leave the device
+        BatchedMPC(ctx, solver=native, prep=prep).compute_control(hs.q0[:warm], hs.state0[:warm, 12:18], hs.target[:warm],
+                                                                  hs.base[:warm])
         torch.cuda.synchronize()
     except Exception as exc:  # noqa: BLE001 - the evals/s line must survive a host-side problem
         err = repr(exc)
@@ -411,7 +413,7 @@ def solve_rate(ctx, mp, sample, threads, rank, world, dist, driver="resident", s
         if not all_ok(err is None):
             return {"error": err or "another rank failed to start its solver"}
         try:
-            bm = BatchedMPC(ctx, solver=native)
+            bm = BatchedMPC(ctx, solver=native, prep=prep)
             t0 = time.perf_counter()
             u = bm.compute_control(hs.q0, hs.state0[:, 12:18], hs.target, hs.base)
             table = gather_result_rows(dist, solve_result_rows(u, bm.last, bm.last_rows), world, rank, ctx.device)

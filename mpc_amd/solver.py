@@ -228,17 +228,38 @@ class BatchedMPC:
         (default: the in-process BatchedSLSQP; pass a ``mpc_amd.pool.SolverPool`` to use more cores).
         `prep`: where the per-tick inputs are assembled.  "host" forms the DLS start with numpy in
         the reference's operation order, J^T inv(J J^T + 0.01 I) twist (start points bit-compatible with it); "device" does everything in one
-        launch of ``mpc_prepare_tick`` (start points equal to rounding; for very large batches)."""
-        if prep not in ("host", "device"):
-            raise ValueError("prep must be 'host' or 'device'")
+        launch of ``mpc_prepare_tick`` (start points equal to rounding; for very large batches); "resident" is
+        "device" with nothing but the tick's inputs and outputs crossing PCIe: the start points go from
+        ``mpc_prepare_tick`` straight into the device-resident solve (needs a solver with ``device_io``:
+        ``ResidentSLSQP``), the solutions stay on the device as the next tick's warm start, and only the first control
+        of each comes back (``previous_solution`` fetches them when asked)."""
+        if prep not in ("host", "device", "resident"):
+            raise ValueError("prep must be 'host', 'device' or 'resident'")
+        if prep == "resident" and not getattr(solver, "device_io", False):
+            raise ValueError("prep='resident' needs a solver that keeps start points and solutions on the device (ResidentSLSQP)")
         self.ctx = ctx
         self.prep = prep
         self.solver = solver if solver is not None else BatchedSLSQP(ctx)
-        self.previous_solution: Optional[np.ndarray] = None   # [N, n], NaN rows = no solution yet
+        self._prev_sol: Optional[np.ndarray] = None           # [N, n], NaN rows = no solution yet
+        self._prev_sol_dev: Optional[torch.Tensor] = None     # prep="resident": the same on the device (rows without: zeros)
+        self._have_sol: Optional[np.ndarray] = None           # prep="resident": which rows hold a solution
         self.previous_control: Optional[np.ndarray] = None    # [N, 6], NaN rows = attribute absent
         self.last: Optional[BatchSolveResult] = None     # the solve of the latest tick; None if that tick solved nothing
         self.last_rows: np.ndarray = np.zeros(0, dtype=np.int64)   # controllers (rows) `last` refers to
         self._kin: Optional[BatchedKinematicPredictor] = None
+
+    @property
+    def previous_solution(self) -> Optional[np.ndarray]:
+        """[N, n] the last accepted solution of every controller, NaN rows where there is none yet (ur_mpc.py:178-185)."""
+        if self.prep == "resident" and self._prev_sol_dev is not None:
+            out = self._prev_sol_dev.cpu().numpy()
+            out[~self._have_sol] = np.nan
+            return out
+        return self._prev_sol
+
+    @previous_solution.setter
+    def previous_solution(self, value):
+        self._prev_sol = value
 
     def compute_control(self, q: np.ndarray, ee_pose: np.ndarray, target: np.ndarray, base: np.ndarray) -> np.ndarray:
         """q [N,6], ee_pose [N,6] = [pos, rpy], target [N,6], base [N,12] -> controls [N,6]."""
@@ -246,9 +267,12 @@ class BatchedMPC:
 
         ctx, p = self.ctx, self.ctx.params
         N, n, H = q.shape[0], p.n, p.horizon
-        if self.previous_solution is None:
-            self.previous_solution = np.full((N, n), np.nan)
+        if self.previous_control is None:
+            self._prev_sol = np.full((N, n), np.nan) if self.prep != "resident" else None
             self.previous_control = np.full((N, 6), np.nan)
+            if self.prep == "resident":
+                self._prev_sol_dev = torch.zeros(N, n, dtype=torch.float64, device=ctx.device)
+                self._have_sol = np.zeros(N, dtype=bool)
         out = np.zeros((N, 6))
         active = ~((np.linalg.norm(base[:, 6:9], axis=1) < 0.01) & (np.linalg.norm(base[:, 9:12], axis=1) < 0.01))
         idx = np.nonzero(active)[0]
@@ -262,12 +286,40 @@ class BatchedMPC:
             if self._kin is None:
                 self._kin = BatchedKinematicPredictor(N)
             bt_kin = up(self._kin.predict(idx, base[idx], H, p.dt))
-        prev_sol = self.previous_solution[idx]
-        have_sol = ~np.isnan(prev_sol[:, 0])
+        everyone = len(idx) == N
+        if self.prep == "resident":
+            prev_sol, have_sol = None, self._have_sol[idx]
+        else:
+            prev_sol = self._prev_sol[idx]
+            have_sol = ~np.isnan(prev_sol[:, 0])
         prev_u = self.previous_control[idx]
         have_u = ~np.isnan(prev_u[:, 0])
         u_prev_d = up(np.nan_to_num(prev_u))
         have_u_d = torch.as_tensor(have_u.astype(np.uint8)).to(dev)
+        if self.prep == "resident":
+            idx_d = None if everyone else torch.as_tensor(idx).to(dev)
+            sc, u_init_d, x0_d, _ = ctx.prepare_tick(
+                up(q[idx]), up(ee_pose[idx]), up(base[idx]), up(target[idx]),
+                prev_solution=self._prev_sol_dev if everyone else self._prev_sol_dev[idx_d].contiguous(),
+                has_solution=torch.as_tensor(have_sol.astype(np.uint8)).to(dev), u_prev=u_prev_d, has_prev=have_u_d)
+            if bt_kin is not None:
+                sc.base_traj = bt_kin
+            res = self.solver.solve(sc, x0_d, x_on_device=True)
+            self.last = res
+            ok = res.success
+            u = res.x_dev[:, :6].cpu().numpy()                                  # 48 of the 8 n bytes of a solution
+            u_init = u_init_d.cpu().numpy()
+            u[have_u & ok] = 0.5 * u[have_u & ok] + 0.5 * prev_u[have_u & ok]      # ur_mpc.py:209-212
+            ctrl = np.where(ok[:, None], np.clip(u, -0.5, 0.5), u_init)            # ur_mpc.py:234-241
+            self.previous_control[idx[ok]] = u[ok]
+            if ok.all() and everyone:
+                self._prev_sol_dev.copy_(res.x_dev)
+            elif ok.any():
+                rows_d = torch.as_tensor(idx[ok]).to(dev)
+                self._prev_sol_dev[rows_d] = res.x_dev[torch.as_tensor(np.nonzero(ok)[0]).to(dev)]
+            self._have_sol[idx[ok]] = True
+            out[idx] = ctrl
+            return out
         if self.prep == "device":
             sc, u_init_d, x0_d, _ = ctx.prepare_tick(
                 up(q[idx]), up(ee_pose[idx]), up(base[idx]), up(target[idx]), prev_solution=up(np.nan_to_num(prev_sol)),
@@ -293,6 +345,6 @@ class BatchedMPC:
         u[have_u & ok] = 0.5 * u[have_u & ok] + 0.5 * prev_u[have_u & ok]      # ur_mpc.py:209-212
         ctrl = np.where(ok[:, None], np.clip(u, -0.5, 0.5), u_init)            # ur_mpc.py:234-241
         self.previous_control[idx[ok]] = u[ok]
-        self.previous_solution[idx[ok]] = res.x[ok]
+        self._prev_sol[idx[ok]] = res.x[ok]
         out[idx] = ctrl
         return out

@@ -291,6 +291,41 @@ def test_batched_ticks_with_device_preparation_match_host_preparation():
         q = q + ua * mp.dt
 
 
+def test_resident_ticks_keep_start_points_and_solutions_on_the_device():
+    """prep="resident": mpc_prepare_tick's start points go straight into the device-resident solve and the solutions
+    stay on the device as the next tick's warm start; only the first controls come back.  Same controls, exit modes
+    and previous solutions, bit for bit, as prep="device" with the same solver (which moves both through the host),
+    over four ticks with two controllers idle (early exit) in the first two."""
+    from helpers import host_scenarios
+    from mpc_amd.batch import MpcContext
+    from mpc_amd.device_solver import ResidentSLSQP
+    from mpc_amd.solver import BatchedMPC
+
+    for H, N in ((3, 12), (20, 8)):
+        mp = MpcParams.reference_yaml_defaults(horizon=H)
+        ctx = MpcContext(mp, N, 0)
+        _, hs = host_scenarios(mp, N, motion="angular", cfg_id=31, goal_jitter=0.0 if H == 20 else 0.05)
+        with ResidentSLSQP(ctx) as sa, ResidentSLSQP(ctx) as sb:
+            a, b = BatchedMPC(ctx, solver=sa, prep="device"), BatchedMPC(ctx, solver=sb, prep="resident")
+            with pytest.raises(ValueError):
+                BatchedMPC(ctx, prep="resident")                     # the default solver works through the host
+            q, ee = hs.q0.copy(), hs.state0[:, 12:18].copy()
+            for tick in range(4):
+                base = hs.base.copy()
+                if tick < 2:
+                    base[[1, 5], 6:12] = 0.0                         # platform at rest: ur_mpc.py:108 returns zeros
+                ua = a.compute_control(q, ee, hs.target, base)
+                ub = b.compute_control(q, ee, hs.target, base)
+                np.testing.assert_array_equal(ub, ua)
+                np.testing.assert_array_equal(b.last.status, a.last.status)
+                np.testing.assert_array_equal(b.last.nit, a.last.nit)
+                np.testing.assert_array_equal(b.last_rows, a.last_rows)
+                assert b.last.x is None and a.last.x is not None
+                np.testing.assert_array_equal(b.previous_solution, a.previous_solution)
+                q = q + ua * mp.dt
+            assert np.isnan(a.previous_solution).sum() == 0
+
+
 def test_batched_mpc_with_kinematic_predictor_equals_drop_in_controllers():
     """use_dynamic_model = False (the reference's code default, ur_mpc.py:63): the batched tick with the
     batched kinematic predictor against one drop-in GpuURMPC per controller, three ticks with a moving

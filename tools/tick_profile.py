@@ -1,5 +1,5 @@
 """Dev tool: where the host time of one batched compute_control tick goes (cProfile), resident driver.
-usage: tick_profile.py [N]"""
+usage: tick_profile.py [N] [host|device|resident]"""
 import os, sys; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import cProfile, pstats, time
 import numpy as np, torch
@@ -10,13 +10,14 @@ from mpc_amd.scenarios import DeviceKinematics, make_scenarios
 from mpc_amd.solver import BatchedMPC
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
+prep = sys.argv[2] if len(sys.argv) > 2 else "resident"
 mp = MpcParams.reference_yaml_defaults(horizon=20)
 ctx = MpcContext(mp, N, 0)
 hs = make_scenarios(mp, DeviceKinematics(ctx), N, motion="angular", cfg_id=3, goal_jitter=0.0)
 with ResidentSLSQP(ctx, capacity=N) as solver:
-    BatchedMPC(ctx, solver=solver).compute_control(hs.q0[:32], hs.state0[:32, 12:18], hs.target[:32], hs.base[:32])
+    BatchedMPC(ctx, solver=solver, prep=prep).compute_control(hs.q0[:32], hs.state0[:32, 12:18], hs.target[:32], hs.base[:32])
     torch.cuda.synchronize()
-    bm = BatchedMPC(ctx, solver=solver)
+    bm = BatchedMPC(ctx, solver=solver, prep=prep)
     pr = cProfile.Profile()
     t0 = time.perf_counter()
     pr.enable()
