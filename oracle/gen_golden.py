@@ -266,6 +266,36 @@ def h20_cases(workers=4):
         phase=np.array([c["phase"] for c in ls]), q=np.stack([c["q"] for c in ls]), u=np.stack([c["u"] for c in ls]))
 
 
+def sweep_cases(workers=6):
+    """BASELINE configs[4]'s workload pinned to the reference: rows of the 1,048,576-row sweep
+    (mpc_amd.scenarios.make_sweep: 32 x 32 amplitude x phase lattice x 1,024 goal poses) taken from all over the
+    index range, both platform families, two compute_control ticks of the real reference each."""
+    import multiprocessing as mpx
+
+    from mpc_amd.scenarios import SWEEP_ROWS, make_sweep
+
+    H = 20
+    mp = MpcParams.reference_yaml_defaults(horizon=H)
+    kin = OracleKinematics(COracle(ref_params_from(mp)))
+    picks = {"linear": [0, 1023, 1024 * 37 + 5, 131072 * 3 + 77777, 1024 * 700 + 311, SWEEP_ROWS - 1],
+             "angular": [1, 1024 * 33 + 512, 131072 * 5 + 4242, 1024 * 999 + 1000, SWEEP_ROWS - 1024]}
+    jobs, index, motions = [], [], []
+    for motion, rows in picks.items():
+        for i in rows:
+            hs = make_sweep(mp, kin, i, 1, motion=motion)
+            if not hs.active[0]:
+                continue
+            jobs.append((motion, i, (hs.q0[0], hs.state0[0, 12:18], hs.target[0], hs.base[0])))
+            index.append(i); motions.append(motion)
+    with mpx.get_context("spawn").Pool(workers) as pool:
+        cs = pool.map(_solve_one_h20, jobs)
+    np.savez_compressed(
+        os.path.join(OUT, "solve_H20_sweep.npz"), H=np.int64(H), motion=np.array(motions), index=np.array(index, dtype=np.int64),
+        q0=np.stack([c["q0"] for c in cs]), ee=np.stack([c["ee"] for c in cs]),
+        target=np.stack([c["target"] for c in cs]), base=np.stack([c["base"] for c in cs]),
+        control=np.stack([c["control"] for c in cs]), solution=np.stack([c["solution"] for c in cs]))
+
+
 def base_motion_cases():
     """predict_base_motion of the reference: dynamic model and 3 ticks of the stateful kinematic one."""
     rng = np.random.default_rng(77)
@@ -339,6 +369,9 @@ def main():
     if "--h100" in sys.argv:         # only the configs[3] angular eval fixture
         h100_angular_cases()
         return
+    if "--sweep" in sys.argv:        # only the configs[4] solve fixture
+        sweep_cases()
+        return
     if "--base-cmd" in sys.argv:     # only the commanded-velocity fixture
         base_cmd_cases()
         return
@@ -348,6 +381,7 @@ def main():
     save_solve(solve_cases())
     h20_cases()
     h100_angular_cases()
+    sweep_cases()
 
 
 if __name__ == "__main__":

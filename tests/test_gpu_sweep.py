@@ -12,6 +12,7 @@ import torch
 
 from helpers import assert_cost_close, assert_grad_close, oracle_for, params_for
 from mpc_amd.batch import EvalResult, MpcContext, ScenarioBatch
+from mpc_amd.params import MpcParams
 from mpc_amd.scenarios import SWEEP_ROWS, DeviceKinematics, make_sweep, to_device
 
 pytestmark = pytest.mark.gpu
@@ -126,3 +127,45 @@ def test_sweep_shard_131072_resident_solves():
     # every goal pose of a lattice cell was solved: the cell's rows differ only in the goal
     cell = (first + keep) // 1024
     assert len(np.unique(cell)) >= 100
+
+
+@pytest.mark.parametrize("kind", ["scipy_core", "resident", "resident_tick"])
+def test_sweep_rows_match_the_reference(golden_dir, kind):
+    """configs[4] pinned to the REAL reference: tests/golden/solve_H20_sweep.npz holds two compute_control ticks of the
+    reference (oracle/gen_golden.py --sweep) for eleven rows from all over the 1,048,576-row sweep, both platform
+    families.  The rows are made again here by make_sweep on the device kinematics (their inputs must be the
+    fixture's), solved by the lock-step driver over scipy's core, by the device-resident solver, and by the resident
+    tick (start points from mpc_prepare_tick, warm start kept on the device), and compared at the north star's 1e-6 rad."""
+    import os
+
+    from mpc_amd.batch import MpcContext
+    from mpc_amd.device_solver import ResidentSLSQP
+    from mpc_amd.scenarios import DeviceKinematics, make_sweep
+    from mpc_amd.solver import BatchedMPC
+
+    path = os.path.join(golden_dir, "solve_H20_sweep.npz")
+    if not os.path.exists(path):
+        pytest.fail("solve_H20_sweep.npz missing: python -m oracle.gen_golden --sweep (where /root/reference exists)")
+    g = np.load(path, allow_pickle=False)
+    N = g["q0"].shape[0]
+    assert N >= 10 and set(g["motion"]) == {"linear", "angular"} and g["index"].max() >= (1 << 20) - 1024
+    mp = MpcParams.reference_yaml_defaults(horizon=20)
+    ctx = MpcContext(mp, max_scenarios=N, device=0)
+    kin = DeviceKinematics(ctx)
+    for k in range(N):                                     # the generator of the workload gives the fixture's inputs
+        hs = make_sweep(mp, kin, int(g["index"][k]), 1, motion=str(g["motion"][k]))
+        np.testing.assert_allclose(hs.q0[0], g["q0"][k], rtol=0, atol=1e-12)
+        np.testing.assert_allclose(hs.state0[0, 12:18], g["ee"][k], rtol=0, atol=1e-9)
+        np.testing.assert_allclose(hs.target[0], g["target"][k], rtol=0, atol=1e-9)
+        np.testing.assert_allclose(hs.base[0], g["base"][k], rtol=0, atol=1e-12)
+    solver = None if kind == "scipy_core" else ResidentSLSQP(ctx, capacity=N)
+    try:
+        bm = BatchedMPC(ctx, solver=solver, prep="resident" if kind == "resident_tick" else "host")
+        for tick in range(g["control"].shape[1]):          # tick 1: warm start, damping term, EMA
+            u = bm.compute_control(g["q0"], g["ee"], g["target"], g["base"])
+            assert bm.last.success.all()
+            np.testing.assert_allclose(bm.previous_solution, g["solution"][:, tick], rtol=0, atol=1e-6)
+            np.testing.assert_allclose(u, g["control"][:, tick], rtol=0, atol=1e-6)
+    finally:
+        if solver is not None:
+            solver.close()

@@ -123,6 +123,36 @@ def test_base_motion_with_commanded_velocities_golden(golden_dir):
             np.testing.assert_array_equal(ref.previous_solution, g["solution"][i, tick])
 
 
+def test_sweep_rows_golden(golden_dir):
+    """BASELINE configs[4]: the numpy restatement against the reference's own solves of two rows of the sweep, one per
+    platform family (tests/golden/solve_H20_sweep.npz, oracle/gen_golden.py --sweep), first tick, bit for bit; the rows'
+    inputs are what make_sweep gives with the oracle's kinematics."""
+    from mpc_amd.params import MpcParams
+    from mpc_amd.scenarios import make_sweep
+    from oracle.oracle import OracleKinematics, ref_params_from
+
+    g = _golden(golden_dir, "solve_H20_sweep.npz")
+    H = int(g["H"])
+    mp = MpcParams.reference_yaml_defaults(horizon=H)
+    kin = OracleKinematics(COracle(ref_params_from(mp)))
+    for motion in ("linear", "angular"):
+        i = int(np.nonzero(g["motion"] == motion)[0][1])
+        hs = make_sweep(mp, kin, int(g["index"][i]), 1, motion=motion)
+        np.testing.assert_array_equal(hs.q0[0], g["q0"][i])
+        np.testing.assert_array_equal(hs.state0[0, 12:18], g["ee"][i])
+        np.testing.assert_array_equal(hs.target[0], g["target"][i])
+        np.testing.assert_array_equal(hs.base[0], g["base"][i])
+        ref = NumpyRefMPC(RefParams(horizon=H))
+        b = g["base"][i]
+        u = ref.compute_control({"position": g["q0"][i].copy(), "velocity": np.zeros(6)},
+                                {"position": g["ee"][i, :3].copy(), "orientation": g["ee"][i, 3:].copy()},
+                                {"position": g["target"][i, :3].copy(), "orientation": g["target"][i, 3:].copy()},
+                                {"position": b[0:3].copy(), "orientation": b[3:6].copy(), "linear_velocity": b[6:9].copy(),
+                                 "angular_velocity": b[9:12].copy()})
+        np.testing.assert_array_equal(u, g["control"][i, 0])
+        np.testing.assert_array_equal(ref.previous_solution, g["solution"][i, 0])
+
+
 def test_jacobian_is_derivative_of_fk():
     """The Jacobian provider (this repo's own, unpinned vs MoveIt) is at least self-consistent."""
     rng = np.random.default_rng(5)
