@@ -326,6 +326,33 @@ def test_resident_ticks_keep_start_points_and_solutions_on_the_device():
             assert np.isnan(a.previous_solution).sum() == 0
 
 
+def test_closed_loop_with_the_resident_tick_matches_the_reference_trajectory(golden_dir):
+    """The action server's loop (mpc_action_server.py:77-135) with everything between a tick's inputs and its commands
+    on the device (prep="resident"): four ticks per platform family against the REAL reference's closed-loop
+    trajectories (tests/golden/closed_loop_H20.npz) at 1e-6 rad, and equal to the prep="device" loop bit for bit."""
+    import os
+
+    from mpc_amd.batch import MpcContext
+    from mpc_amd.closed_loop import run_closed_loop
+    from mpc_amd.device_solver import ResidentSLSQP
+
+    g = np.load(os.path.join(golden_dir, "closed_loop_H20.npz"), allow_pickle=False)
+    mp = MpcParams.reference_yaml_defaults(horizon=int(g["H"]))
+    ctx = MpcContext(mp, 4, 0)
+    for i, motion in enumerate(g["motion"]):
+        q0 = g["q0"][i][None]
+        amp, ph = np.array([float(g["amplitude"][i])]), np.array([float(g["phase"][i])])
+        ticks = g["u"][i].shape[0]
+        with ResidentSLSQP(ctx) as solver:
+            res = run_closed_loop(ctx, q0, str(motion), amp, ph, ticks=ticks, solver=solver, prep="resident")
+            dev = run_closed_loop(ctx, q0, str(motion), amp, ph, ticks=ticks, solver=solver, prep="device")
+        assert res.converged.all()
+        np.testing.assert_allclose(res.q[:, 0], g["q"][i], rtol=0, atol=1e-6)
+        np.testing.assert_allclose(res.u[:, 0], g["u"][i], rtol=0, atol=1e-6)
+        np.testing.assert_array_equal(res.q, dev.q)
+        np.testing.assert_array_equal(res.u, dev.u)
+
+
 def test_batched_mpc_with_kinematic_predictor_equals_drop_in_controllers():
     """use_dynamic_model = False (the reference's code default, ur_mpc.py:63): the batched tick with the
     batched kinematic predictor against one drop-in GpuURMPC per controller, three ticks with a moving
