@@ -3,7 +3,10 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include "../../mpc_amd/csrc/lsq_wave.hpp"
-constexpr int N = 120, TRI = N * (N + 1) / 2 + 1;
+#ifndef NN
+#define NN 120
+#endif
+constexpr int N = NN, TRI = N * (N + 1) / 2 + 1;
 __global__ void __launch_bounds__(256) bench(unsigned long long *cyc, double *out, int reps)
 {
     __shared__ double E[TRI], x[N], g[N], ff[N], vv[N], ys[2 * N];
