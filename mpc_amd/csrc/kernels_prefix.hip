@@ -42,6 +42,7 @@ struct PrefixArgs {
     // ROWS form (device-resident solves): evaluate rows list[0 .. *count_dev) of every array in place
     const int32_t *list;
     const int32_t *count_dev;
+    int single_row = -1;  // ROWS form without a list (kernels_team.hip): this one row
 };
 
 // How the forward-difference work is organised:
@@ -249,21 +250,26 @@ __device__ __forceinline__ double pick6(const double (&a)[6], int j)
     return v;
 }
 
-template <int MODE, bool SAME_DT, int MAXT, bool ROWS = false>
-__global__ __launch_bounds__(MAXT) void prefix_kernel(const mpc_params P, const PrefixArgs A)
+// The work of one workgroup (thread tid of bs, scenarios s0 .. s0 + A.S - 1 of the batch or of the request list, lds:
+// the workgroup's 16-byte aligned LDS of geometry(P, MODE).lds bytes).  A function of its own so that a kernel which
+// does more than evaluate (kernels_team.hip: whole solves per workgroup) can run the very same text; every thread of
+// the workgroup must call it (it contains workgroup barriers).
+template <int MODE, bool SAME_DT, bool ROWS>
+__device__ __forceinline__ void prefix_body(const mpc_params &P, const PrefixArgs &A, double *lds, const int tid, const int bs,
+                                            const int s0)
 {
-    extern __shared__ __align__(16) double lds[];
     const int H = P.horizon, n = 6 * H, m = 12 * (H + 1), L = H + 1;
-    const int tid = threadIdx.x, bs = blockDim.x;
     constexpr bool FD = MODE != kEval;
     const Layout Y = make_layout(H, MODE, SAME_DT);
     double *dec = lds;  // [H], shared by the scenarios of the workgroup
     double *scen = lds + ((H + 1) & ~1);
-    const int s0 = blockIdx.x * A.S;
-    const int ns = min(A.S, (ROWS ? *A.count_dev : A.sc.count) - s0);
+    const bool one = ROWS && A.single_row >= 0;
+    const int ns = one ? 1 : min(A.S, (ROWS ? *A.count_dev : A.sc.count) - s0);
     if (ROWS && ns <= 0) return;                 // grid sized by an upper bound of the list length
     // row of local scenario ls in the caller's arrays: consecutive, or taken from the request list
-    auto row = [&](int ls) -> size_t { return ROWS ? (size_t)A.list[s0 + ls] : (size_t)(s0 + ls); };
+    auto row = [&](int ls) -> size_t {
+        return ROWS ? (one ? (size_t)A.single_row : (size_t)A.list[s0 + ls]) : (size_t)(s0 + ls);
+    };
 
     // ---- stage the scenarios' inputs: rows of consecutive scenarios are contiguous in HBM ------
     for (int i = tid; i < H; i += bs) dec[i] = A.decay[i];
@@ -552,6 +558,13 @@ __global__ __launch_bounds__(MAXT) void prefix_kernel(const mpc_params P, const 
             }
         }
     }
+}
+
+template <int MODE, bool SAME_DT, int MAXT, bool ROWS = false>
+__global__ __launch_bounds__(MAXT) void prefix_kernel(const mpc_params P, const PrefixArgs A)
+{
+    extern __shared__ __align__(16) double lds[];
+    prefix_body<MODE, SAME_DT, ROWS>(P, A, lds, (int)threadIdx.x, (int)blockDim.x, (int)blockIdx.x * A.S);
 }
 
 // kCompact's second half: one workgroup per (scenario, step jj) writes the six dense columns of that

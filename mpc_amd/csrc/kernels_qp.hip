@@ -86,6 +86,69 @@ qp_kernel(int H, int count, const double *__restrict__ l, const double *__restri
     }
 }
 
+// One request served by the team: the factor staged (reset, or from l), BFGS-updated and written back as the flags
+// say, the QP solved, the Lagrangian gradient kept.  lo / hi / s_in / s_out: the request's own rows.  Returns the QP's
+// mode.  (A function of its own: kernels_team.hip runs it inside whole solves.)
+template <bool kLds, bool kAug>
+__device__ __forceinline__ int qp_serve(const HipTeam<kLds> &T, const lsqspmd::Work &W, int H, int fl, double *l, const double *g,
+                                        const double *c, const double *nz, double *r, double *v, const double *lo,
+                                        const double *hi, const double *s_in, double *s_out)
+{
+    const int n = 6 * H, m = 12 * (H + 1), ldl = (n + 1) * n / 2 + 1;
+    (void)m;
+    QP_MARK_START(T);
+    if (fl & 1) {                                            // the factor of the identity
+        PAR_FOR(T, e, 0, ldl - 1) W.E[e] = 0.0;
+        T.sync();
+        PAR_FOR(T, i, 0, n) W.E[i * n - (i * (i - 1)) / 2] = 1.0;
+    } else {
+        // the factor comes from global memory: sixteen loads in flight per thread, not one
+        const int per = 16 * (int)blockDim.x;
+        int e0 = 0;
+        for (; e0 + per <= ldl - 1; e0 += per) {
+            double t[16];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) t[q] = l[e0 + q * (int)blockDim.x + (int)threadIdx.x];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) W.E[e0 + q * (int)blockDim.x + (int)threadIdx.x] = t[q];
+        }
+        for (int e = e0 + (int)threadIdx.x; e < ldl - 1; e += (int)blockDim.x) W.E[e] = l[e];
+    }
+    if (fl & 2) {
+        PAR_FOR(T, i, 0, n) {
+            W.bb[i] = v[i];
+            W.zz[i] = s_in[i];
+        }
+        T.sync();
+        QP_MARK(T, 8);    // staging in
+        lsqspmd::bfgs_update(T, W, H, W.E, g, nz, r, W.bb, W.zz, W.xs);
+        QP_MARK(T, 9);    // BFGS update
+    }
+    T.sync();
+    if (fl & 3) PAR_FOR(T, e, 0, ldl - 1) l[e] = W.E[e];
+    T.sync();
+    QP_MARK(T, 10);       // staging in (no update) / factor written back
+    int md;
+    if constexpr (kAug) {
+        if (threadIdx.x == 0) {
+            double rho = 100.0;                              // Kraft's l(n3), ten times larger per failed attempt
+            for (int k = (fl >> 3) & 7; k > 0; --k) rho = 10.0 * rho;
+            W.E[ldl - 1] = rho;
+        }
+        T.sync();
+        md = lsqspmd::lsq<true>(T, W, H, g, c, nz, lo, hi, s_out, r, r + m);
+    } else {
+        md = lsqspmd::lsq(T, W, H, g, c, nz, lo, hi, s_out, r);
+    }
+    T.sync();
+    if (md == 1) {
+        PAR_FOR(T, i, 0, n) {
+            v[i] = g[i] - lsqspmd::jac_column_dot(H, nz, r, i);
+        }
+    }
+    return md;
+}
+
 // One major-iteration step of an offloaded solve (slsqp_core.h: slsqp_state.offload) for the problems listed
 // in `index`: reset or BFGS-update the problem's LDL' factor, solve the QP, keep the new multipliers and the
 // Lagrangian gradient v = g - (dc/dx)^T r for the next update.  State rows are addressed by problem, the
@@ -143,57 +206,8 @@ qp_step_kernel(int H, int count, int rows, const int32_t *__restrict__ index, co
             }
             continue;
         }
-        QP_MARK_START(T);
-        if (fl & 1) {                                            // the factor of the identity
-            PAR_FOR(T, e, 0, ldl - 1) W.E[e] = 0.0;
-            T.sync();
-            PAR_FOR(T, i, 0, n) W.E[i * n - (i * (i - 1)) / 2] = 1.0;
-        } else {
-            // the factor comes from global memory: sixteen loads in flight per thread, not one
-            const int per = 16 * (int)blockDim.x;
-            int e0 = 0;
-            for (; e0 + per <= ldl - 1; e0 += per) {
-                double t[16];
-#pragma unroll
-                for (int q = 0; q < 16; ++q) t[q] = l[e0 + q * (int)blockDim.x + (int)threadIdx.x];
-#pragma unroll
-                for (int q = 0; q < 16; ++q) W.E[e0 + q * (int)blockDim.x + (int)threadIdx.x] = t[q];
-            }
-            for (int e = e0 + (int)threadIdx.x; e < ldl - 1; e += (int)blockDim.x) W.E[e] = l[e];
-        }
-        if (fl & 2) {
-            PAR_FOR(T, i, 0, n) {
-                W.bb[i] = v[i];
-                W.zz[i] = s_in[q * n + i];
-            }
-            T.sync();
-            QP_MARK(T, 8);    // staging in
-            lsqspmd::bfgs_update(T, W, H, W.E, g, nz, r, W.bb, W.zz, W.xs);
-            QP_MARK(T, 9);    // BFGS update
-        }
-        T.sync();
-        if (fl & 3) PAR_FOR(T, e, 0, ldl - 1) l[e] = W.E[e];
-        T.sync();
-        QP_MARK(T, 10);       // staging in (no update) / factor written back
-        int md;
-        if constexpr (kAug) {
-            if (threadIdx.x == 0) {
-                double rho = 100.0;                              // Kraft's l(n3), ten times larger per failed attempt
-                for (int k = (fl >> 3) & 7; k > 0; --k) rho = 10.0 * rho;
-                W.E[ldl - 1] = rho;
-            }
-            T.sync();
-            md = lsqspmd::lsq<true>(T, W, H, g, c, nz, lo + q * n, hi + q * n, s_out + q * n, r, r + m);
-        } else {
-            md = lsqspmd::lsq(T, W, H, g, c, nz, lo + q * n, hi + q * n, s_out + q * n, r);
-        }
-        T.sync();
-        if (md == 1) {
-            PAR_FOR(T, i, 0, n) {
-                v[i] = g[i] - lsqspmd::jac_column_dot(H, nz, r, i);
-            }
-            if (!kRows) PAR_FOR(T, i, 0, m) r_out[q * m + i] = r[i];
-        }
+        const int md = qp_serve<kLds, kAug>(T, W, H, fl, l, g, c, nz, r, v, lo + q * n, hi + q * n, s_in + q * n, s_out + q * n);
+        if (md == 1 && !kRows) PAR_FOR(T, i, 0, m) r_out[q * m + i] = r[i];
         if (threadIdx.x == 0) mode[q] = md;
         __syncthreads();
         QP_MARK_START(T);

@@ -219,9 +219,120 @@ __global__ void solve_begin_kernel(const mpc_params P, SolveWorkspace W, int cou
 // increment the same word, and L2 serialises them).
 constexpr int kBodyWaves = 4;      // problems per workgroup of solve_body_kernel, one wavefront each (fewer if LDS is short)
 
+// ---- one call of the body for one problem, by one wavefront: the pieces ---------------------------------------------
+// (solve_body_kernel strings them together for the problems of a lock-step round; kernels_team.hip for one problem after
+//  the other inside a workgroup that runs whole solves)
+struct BodyVectors { double *x, *x0, *s, *u, *v, *g, *c, *mu, *r; };       // LDS: 6 n + 3 m doubles
+__device__ __forceinline__ BodyVectors body_vectors(double *base, int n, int m)
+{
+    BodyVectors B;
+    B.x = base; B.x0 = B.x + n; B.s = B.x0 + n; B.u = B.s + n; B.v = B.u + n; B.g = B.v + n; B.c = B.g + n; B.mu = B.c + m;
+    B.r = B.mu + m;
+    return B;
+}
+struct BodyScalars { int mode, iter, qp_mode; double acc, fval, qp_delta; };
+// the problem's scalars are requested with the vectors, not after the barrier where they are used (a second and, for
+// the QP's answer, a third trip to memory on a kernel that is little else than latency)
+__device__ __forceinline__ BodyScalars body_scalars(const SolveWorkspace &W, int p, int mg, int m)
+{
+    BodyScalars Z;
+    Z.mode = W.MODE[p];
+    Z.iter = W.ITER[p];
+    Z.qp_mode = W.QPMODE[p];
+    Z.acc = W.ACC[p];
+    Z.fval = W.F[p];
+    Z.qp_delta = W.RM[(size_t)p * mg + m];                          // an augmented problem's extra entry of the step
+    return Z;
+}
+// every load of up to 256 entries of the seven vectors is issued before the first LDS store: one trip to memory per
+// pass (a single pass at H = 20) instead of one per vector and stride
+__device__ __forceinline__ void body_stage(const SolveWorkspace &W, size_t pp, int n, int m, int mg, int lane, const BodyVectors &B)
+{
+    const double *gx = W.X + pp * n, *gx0 = W.X0 + pp * n, *gs = W.S + pp * n, *gmu = W.MU + pp * m;
+    const double *gg = W.G + pp * n, *gc = W.C + pp * m, *gr = W.RM + pp * mg;
+    for (int base = 0; base < m; base += 256) {
+        double rx[4], rx0[4], rs[4], rg[4], rc[4], rmu[4], rr[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int i = base + 64 * q + lane;
+            const bool in_n = i < n, in_m = i < m;
+            rx[q] = in_n ? gx[i] : 0.0;
+            rx0[q] = in_n ? gx0[i] : 0.0;
+            rs[q] = in_n ? gs[i] : 0.0;
+            rg[q] = in_n ? gg[i] : 0.0;
+            rc[q] = in_m ? gc[i] : 0.0;
+            rmu[q] = in_m ? gmu[i] : 0.0;
+            rr[q] = in_m ? gr[i] : 0.0;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int i = base + 64 * q + lane;
+            if (i < n) { B.x[i] = rx[q]; B.x0[i] = rx0[q]; B.s[i] = rs[q]; B.g[i] = rg[q]; }
+            if (i < m) { B.c[i] = rc[q]; B.mu[i] = rmu[q]; B.r[i] = rr[q]; }
+        }
+    }
+}
+// The whole wavefront runs the body (same scalars in every lane, the vectors shared out); its first lane files the
+// scalars away.  Returns what the problem asks for next: 0 f and c, 1 derivatives, 2 its QP, -1 nothing (finished);
+// *box_fresh: the body formed the QP's box in u, v (not so when it asks again, augmented or deferred).
+// (A problem whose augmented QP met the plain QP kernel in a round without the augmented one - mpc_solve_rounds
+//  launches that only once such a request has been seen - has not been served: it asks again, as it stands.)
+__device__ __forceinline__ int body_run(const SolveWorkspace &W, int p, int n, int m, int lane, BodyScalars Z, const BodyVectors &B,
+                                        bool *box_fresh)
+{
+    *box_fresh = false;
+    if (Z.mode == MPC_SLSQP_MODE_QP && Z.qp_mode == MPC_QP_MODE_DEFERRED) return 2;
+    slsqp_state S = W.ST[p];
+    if (Z.mode == MPC_SLSQP_MODE_QP) {
+        S.qp_mode = Z.qp_mode;
+        S.qp_delta = Z.qp_delta;
+    }
+    int mode = Z.mode, iter = Z.iter;
+    double acc = Z.acc;
+#if defined(__HIP_DEVICE_COMPILE__)
+    slsqp_body_device(m, 0, m, n, B.x, W.lb, W.ub, Z.fval, B.c, B.g, nullptr, &acc, &iter, &mode, B.r, nullptr, B.x0, B.mu, B.s,
+                      B.u, B.v, nullptr, nullptr, &S);
+#endif
+    int kind = -1;
+    if (mode == 1) kind = 0;
+    else if (mode == -1) kind = 1;
+    else if (mode == MPC_SLSQP_MODE_QP) kind = 2;
+    *box_fresh = kind == 2 && !S.qp_aug;
+    if (lane == 0) {
+        W.ST[p] = S;
+        W.ITER[p] = iter;
+        W.ACC[p] = acc;
+        W.MODE[p] = mode;                                           // not 1, -1 or QP: finished, this is the exit mode
+        if (kind == 2) W.QPFLAGS[p] = MPC_QP_FLAGS_OF(&S);
+    }
+    return kind;
+}
+// what the body changed goes back to the problem's rows; the QP's box or the clipped evaluation point with it
+__device__ __forceinline__ void body_store(const SolveWorkspace &W, size_t pp, int n, int m, int lane, const BodyVectors &B, int kind,
+                                           bool box_fresh)
+{
+    double *gx = W.X + pp * n, *gx0 = W.X0 + pp * n, *gs = W.S + pp * n, *gmu = W.MU + pp * m;
+    for (int i = lane; i < n; i += 64) { gx[i] = B.x[i]; gx0[i] = B.x0[i]; gs[i] = B.s[i]; }
+    for (int i = lane; i < m; i += 64) gmu[i] = B.mu[i];
+    if (kind == 2) {
+        if (box_fresh) {
+            double *gu = W.LO + pp * n, *gv = W.HI + pp * n;
+            for (int i = lane; i < n; i += 64) { gu[i] = B.u[i]; gv[i] = B.v[i]; }
+        }
+    } else if (kind >= 0) {
+        double *xe = W.XE + pp * n;                                 // the point to evaluate, inside the box (_clip_x_for_func)
+        for (int i = lane; i < n; i += 64) {
+            double t = B.x[i];
+            t = t < W.lb[i] ? W.lb[i] : t;
+            t = t > W.ub[i] ? W.ub[i] : t;
+            xe[i] = t;
+        }
+    }
+}
+
 // (three workgroups per CU is what their LDS allows at H = 20: the registers are held to that, 168 per lane)
 __global__ __launch_bounds__(64 * kBodyWaves, 3) void solve_body_kernel(int H, SolveWorkspace W, int old, int cs_old, int cs_new,
-                                                                     int cs_next)
+                                                                        int cs_next)
 {
     extern __shared__ double body_lds[];
     __shared__ int ask[kBodyWaves];          // what each wavefront's problem asks for: 0 f, 1 derivatives, 2 QP, -1 nothing
@@ -242,82 +353,18 @@ __global__ __launch_bounds__(64 * kBodyWaves, 3) void solve_body_kernel(int H, S
     else if ((k -= cG) < cQ) p = W.LIST_Q[old][k];
     p = __builtin_amdgcn_readfirstlane(p);   // one problem per wavefront: said so, its scalars then live in scalar registers
     const bool live = p >= 0;                // a wavefront beyond the lists only takes part in the barriers
-    const size_t per = (size_t)(6 * n + 3 * m);
-    double *x = body_lds + wave * per, *x0 = x + n, *s = x0 + n, *u = s + n, *v = u + n, *g = v + n, *c = g + n, *mu = c + m,
-           *r = mu + m;
+    const BodyVectors B = body_vectors(body_lds + wave * (size_t)(6 * n + 3 * m), n, m);
     const size_t pp = live ? (size_t)p : 0;
-    double *gx = W.X + pp * n, *gx0 = W.X0 + pp * n, *gs = W.S + pp * n, *gmu = W.MU + pp * m;
-    // the problem's scalars are requested here, with the vectors, not after the barrier where they are used (a second
-    // and, for the QP's answer, a third trip to memory on a kernel that is little else than latency)
-    int mode = 0, iter = 0, qp_mode = 0;
-    double acc = 0.0, fval = 0.0, qp_delta = 0.0;
-    (void)fval;                              // (read in the device pass only)
+    BodyScalars Z = {};
     if (live) {
-        mode = W.MODE[p];
-        iter = W.ITER[p];
-        qp_mode = W.QPMODE[p];
-        acc = W.ACC[p];
-        fval = W.F[p];
-        qp_delta = W.RM[pp * mg + m];                               // an augmented problem's extra entry of the step
-    }
-    if (live) {
-        // every load of up to 256 entries of the seven vectors is issued before the first LDS store: one trip to
-        // memory per pass (a single pass at H = 20) instead of one per vector and stride
-        const double *gg = W.G + pp * n, *gc = W.C + pp * m, *gr = W.RM + pp * mg;
-        for (int base = 0; base < m; base += 256) {
-            double rx[4], rx0[4], rs[4], rg[4], rc[4], rmu[4], rr[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int i = base + 64 * q + lane;
-                const bool in_n = i < n, in_m = i < m;
-                rx[q] = in_n ? gx[i] : 0.0;
-                rx0[q] = in_n ? gx0[i] : 0.0;
-                rs[q] = in_n ? gs[i] : 0.0;
-                rg[q] = in_n ? gg[i] : 0.0;
-                rc[q] = in_m ? gc[i] : 0.0;
-                rmu[q] = in_m ? gmu[i] : 0.0;
-                rr[q] = in_m ? gr[i] : 0.0;
-            }
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int i = base + 64 * q + lane;
-                if (i < n) { x[i] = rx[q]; x0[i] = rx0[q]; s[i] = rs[q]; g[i] = rg[q]; }
-                if (i < m) { c[i] = rc[q]; mu[i] = rmu[q]; r[i] = rr[q]; }
-            }
-        }
+        Z = body_scalars(W, p, mg, m);
+        body_stage(W, pp, n, m, mg, lane, B);
     }
     __syncthreads();
-    bool box_fresh = false;                  // the body formed the QP's box in u, v (not so when it asks again, augmented)
+    bool box_fresh = false;
     {
-        // the whole wavefront runs the body (same scalars in every lane, the vectors shared out); its first lane files
-        // the scalars away
         int kind = -1;
-        // (a problem whose augmented QP met the plain QP kernel in a round without the augmented one - mpc_solve_rounds
-        //  launches that only once such a request has been seen - has not been served: it asks again, as it stands)
-        const bool deferred = live && mode == MPC_SLSQP_MODE_QP && qp_mode == MPC_QP_MODE_DEFERRED;
-        if (deferred) kind = 2;
-        if (live && !deferred) {
-            slsqp_state S = W.ST[p];
-            if (mode == MPC_SLSQP_MODE_QP) {
-                S.qp_mode = qp_mode;
-                S.qp_delta = qp_delta;
-            }
-#if defined(__HIP_DEVICE_COMPILE__)
-            slsqp_body_device(m, 0, m, n, x, W.lb, W.ub, fval, c, g, nullptr, &acc, &iter, &mode, r, nullptr, x0, mu, s, u, v,
-                              nullptr, nullptr, &S);
-#endif
-            if (mode == 1) kind = 0;
-            else if (mode == -1) kind = 1;
-            else if (mode == MPC_SLSQP_MODE_QP) kind = 2;
-            box_fresh = kind == 2 && !S.qp_aug;
-            if (lane == 0) {
-                W.ST[p] = S;
-                W.ITER[p] = iter;
-                W.ACC[p] = acc;
-                W.MODE[p] = mode;                                   // not 1, -1 or QP: finished, this is the exit mode
-                if (kind == 2) W.QPFLAGS[p] = MPC_QP_FLAGS_OF(&S);
-            }
-        }
+        if (live) kind = body_run(W, p, n, m, lane, Z, B, &box_fresh);
         if (lane == 0) ask[wave] = kind;
     }
     __syncthreads();
@@ -336,22 +383,7 @@ __global__ __launch_bounds__(64 * kBodyWaves, 3) void solve_body_kernel(int H, S
         for (int w = 0; w < wave; ++w) slot += ask[w] == kind;
         (kind == 0 ? W.LIST_F : kind == 1 ? W.LIST_G : W.LIST_Q)[1 - old][slot] = p;
     }
-    for (int i = lane; i < n; i += 64) { gx[i] = x[i]; gx0[i] = x0[i]; gs[i] = s[i]; }
-    for (int i = lane; i < m; i += 64) gmu[i] = mu[i];
-    if (kind == 2) {
-        if (box_fresh) {
-            double *gu = W.LO + pp * n, *gv = W.HI + pp * n;
-            for (int i = lane; i < n; i += 64) { gu[i] = u[i]; gv[i] = v[i]; }
-        }
-    } else if (kind >= 0) {
-        double *xe = W.XE + pp * n;                                 // the point to evaluate, inside the box (_clip_x_for_func)
-        for (int i = lane; i < n; i += 64) {
-            double t = x[i];
-            t = t < W.lb[i] ? W.lb[i] : t;
-            t = t > W.ub[i] ? W.ub[i] : t;
-            xe[i] = t;
-        }
-    }
+    body_store(W, pp, n, m, lane, B, kind, box_fresh);
 }
 
 __global__ void solve_result_kernel(int H, SolveWorkspace W, int count, int slot, double *__restrict__ x,
