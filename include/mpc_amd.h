@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MPC_AMD_ABI_VERSION 9
+#define MPC_AMD_ABI_VERSION 10
 #define MPC_MAX_HORIZON 255
 
 typedef enum mpc_status {
@@ -268,6 +268,17 @@ int mpc_solve_rounds(mpc_ctx *ctx, const mpc_scenarios *sc, void *ws, int rows, 
                      int32_t *unfinished, void *stream);
 int mpc_solve_result(mpc_ctx *ctx, int count, void *ws, int rows, size_t ws_bytes, double *x, double *fun, int32_t *nit,
                      int32_t *status, int32_t *stats, void *stream);
+/* The same solves without the lock step, for batches too small to fill the rounds (a round costs at least one QP's
+ * latency however few problems ask for one; a single controller's tick is ~100 rounds of five launches): ONE launch in
+ * which persistent workgroups take a problem each from a queue and run it to its end - body, evaluations, BFGS update +
+ * QP, Kraft's augmented problem included - with the device code of the lock-step kernels on the same workspace rows,
+ * so results are those of mpc_solve_rounds bit for bit.  Call it after mpc_solve_begin instead of mpc_solve_rounds
+ * (same sc, ws; maxiter as given to mpc_solve_begin: it bounds the work per problem), then mpc_solve_result.
+ * *unfinished (device or pinned host memory, may be NULL) receives the number of problems that met that bound (0).
+ * H <= 21 (the QP's vectors in LDS, one wavefront per evaluation); MPC_ERR_UNSUPPORTED otherwise.  At H = 20 one
+ * controller's solve takes ~5 ms instead of ~9, 4,096 take ~65 ms instead of 106; from ~16,384 on the rounds win. */
+int mpc_solve_run(mpc_ctx *ctx, const mpc_scenarios *sc, void *ws, int rows, size_t ws_bytes, int maxiter, int32_t *unfinished,
+                  void *stream);
 
 /* Active-set gather for lock-step solves: scipy's driver evaluates a problem only when its SLSQP core
  * asks (mode 1 / -1, _slsqp_py.py:427-456), so each round of a batched solve touches a changing subset

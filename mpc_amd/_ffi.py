@@ -11,14 +11,14 @@ LIB_PATH = os.environ.get("MPC_AMD_LIB") or os.path.join(_HERE, "libmpc_amd.so")
 MPC_OK = 0
 ALGO_AUTO, ALGO_ROLLOUT, ALGO_PREFIX = 0, 1, 2
 MAX_HORIZON = 255
-ABI_VERSION = 9
+ABI_VERSION = 10
 STATIC_SCRATCH_DOUBLES = 2 * 1024 * 1024
 
 EXPORTS = (
     "mpc_abi_version", "mpc_ctx_create", "mpc_ctx_destroy", "mpc_set_params", "mpc_eval", "mpc_eval_fd",
     "mpc_jacobian", "mpc_fk", "mpc_predict_base_dynamic", "mpc_predict_base_dynamic_cmd", "mpc_prepare_tick", "mpc_qp_solve", "mpc_qp_step", "mpc_gather_scenarios", "mpc_jacobian_nz_count", "mpc_eval_fd_nz",
     "mpc_expand_jacobian", "mpc_last_error", "mpc_eval_fd_static",
-    "mpc_sincos_probe", "mpc_ordered_sum_probe", "mpc_solve_workspace_bytes", "mpc_solve_begin", "mpc_solve_rounds", "mpc_solve_result",
+    "mpc_sincos_probe", "mpc_ordered_sum_probe", "mpc_solve_workspace_bytes", "mpc_solve_begin", "mpc_solve_rounds", "mpc_solve_run", "mpc_solve_result",
 )
 
 
@@ -111,6 +111,8 @@ def load():
     L.mpc_solve_begin.argtypes = [vp, C.POINTER(MpcScenariosC), vp, C.c_double, ip, vp, ip, C.c_size_t, vp]
     L.mpc_solve_rounds.restype = ip
     L.mpc_solve_rounds.argtypes = [vp, C.POINTER(MpcScenariosC), vp, ip, C.c_size_t, ip, ip, vp, vp]
+    L.mpc_solve_run.restype = ip
+    L.mpc_solve_run.argtypes = [vp, C.POINTER(MpcScenariosC), vp, ip, C.c_size_t, ip, vp, vp]
     L.mpc_solve_result.restype = ip
     L.mpc_solve_result.argtypes = [vp, ip, vp, ip, C.c_size_t, vp, vp, vp, vp, vp, vp]
     L.mpc_last_error.restype = C.c_char_p

@@ -24,6 +24,7 @@ _UNITS = {
     "kernels_prefix.hip": _STRICT,  # fused multiply-adds are written out with fma() there
     "kernels_qp.hip": _STRICT,      # bit-identical to the host SLSQP core
     "kernels_slsqp.hip": _STRICT,   # Kraft's body on the device: the host core's text, one rounding per operation
+    "kernels_team.hip": _STRICT,    # whole solves per workgroup: the device code of the three units above, once more
 }
 _COMMON = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function",
            "-I" + os.path.join(_ROOT, "include"), "-I" + CSRC]

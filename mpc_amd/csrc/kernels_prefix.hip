@@ -736,6 +736,7 @@ hipError_t launch_mode(const mpc_params &P, const PrefixArgs &A, const Geometry 
 
 }  // namespace
 
+#ifndef MPC_TEAM_UNIT       // (kernels_team.hip includes this file for its device code only)
 namespace mpck {
 
 bool prefix_supported(const mpc_params &P) { return ur_pattern(P) && (fused_ok(P) || compact_ok(P)); }
@@ -898,3 +899,4 @@ hipError_t launch_prefix(const mpc_params &P, const double *decay, const mpc_sce
 }
 
 }  // namespace mpck
+#endif  // MPC_TEAM_UNIT

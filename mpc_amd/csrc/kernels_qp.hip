@@ -240,6 +240,7 @@ size_t lds_bytes(int H, int aug = 0)
 
 }  // namespace
 
+#ifndef MPC_TEAM_UNIT       // (kernels_team.hip includes this file for its device code only)
 namespace mpck {
 
 int qp_teams_per_cu(int H)
@@ -324,3 +325,4 @@ hipError_t launch_qp(int H, int count, int teams, const double *l, const double 
 }
 
 }  // namespace mpck
+#endif  // MPC_TEAM_UNIT

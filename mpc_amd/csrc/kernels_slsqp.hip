@@ -129,6 +129,7 @@ __device__ __forceinline__ void slsqp_body_device(int m, int meq, int la, int n,
 
 }  // namespace
 
+#ifndef MPC_TEAM_UNIT       // (kernels_team.hip includes this file for its device code only)
 namespace mpck {
 
 SolveWorkspace carve_solve_workspace(void *base, int H, int rows)
@@ -154,6 +155,7 @@ SolveWorkspace carve_solve_workspace(void *base, int H, int rows)
 }
 
 }  // namespace mpck
+#endif  // MPC_TEAM_UNIT
 
 namespace {
 
@@ -415,6 +417,7 @@ __global__ void solve_count_kernel(int32_t *__restrict__ c, const int32_t *__res
 
 }  // namespace
 
+#ifndef MPC_TEAM_UNIT       // (kernels_team.hip includes this file for its device code only)
 namespace mpck {
 
 size_t solve_workspace_bytes(int H, int rows) { return carve_solve_workspace(nullptr, H, rows).bytes; }
@@ -489,3 +492,4 @@ hipError_t launch_solve_count(const SolveWorkspace &W, int slot, hipStream_t str
 }
 
 }  // namespace mpck
+#endif  // MPC_TEAM_UNIT

@@ -616,6 +616,33 @@ int mpc_solve_rounds(mpc_ctx *ctx, const mpc_scenarios *sc, void *ws, int rows, 
     return MPC_OK;
 }
 
+int mpc_solve_run(mpc_ctx *ctx, const mpc_scenarios *sc, void *ws, int rows, size_t ws_bytes, int maxiter, int32_t *unfinished,
+                  void *stream)
+{
+    if (!sc) return fail(ctx, MPC_ERR_INVALID_ARG, "scenarios is NULL");
+    int rc = check_solve(ctx, sc->count, ws, rows, ws_bytes);
+    if (rc) return rc;
+    if (sc->count > 0 && (!sc->state0 || !sc->target || !sc->base_traj || !sc->Jc))
+        return fail(ctx, MPC_ERR_INVALID_ARG, "state0/target/base_traj/Jc must be non-NULL");
+    if (maxiter < 1) return fail(ctx, MPC_ERR_INVALID_ARG, "maxiter must be positive");
+    if (!mpck::solve_team_supported(ctx->params))
+        return fail(ctx, MPC_ERR_UNSUPPORTED, "mpc_solve_run needs the QP's vectors in LDS and one wavefront per evaluation (H <= 21)");
+    if (sc->count == 0) return MPC_OK;
+    if (!ctx->d_qp_work || ctx->solve_ws != ws || ctx->solve_round != 0)
+        return fail(ctx, MPC_ERR_INVALID_ARG, "mpc_solve_run follows mpc_solve_begin on this context and workspace, before any round");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    MPC_HIP(ctx, hipSetDevice(ctx->device));
+    const mpck::SolveWorkspace W = mpck::carve_solve_workspace(ws, ctx->horizon, rows);
+    hipError_t e = mpck::launch_solve_team(ctx->params, ctx->d_decay, *sc, W, sc->count, maxiter, ctx->qp_teams, ctx->d_qp_work,
+                                           ctx->d_qp_iwork, st);
+    if (e == hipSuccess && unfinished) e = hipMemcpyAsync(unfinished, W.counters + 3, sizeof(int32_t), hipMemcpyDefault, st);
+    if (e != hipSuccess) {
+        ctx->solve_ws = nullptr;               // the state is as far as the launches got: begin again
+        return hip_fail(ctx, e, "mpc_solve_run");
+    }
+    return MPC_OK;
+}
+
 int mpc_solve_result(mpc_ctx *ctx, int count, void *ws, int rows, size_t ws_bytes, double *x, double *fun, int32_t *nit,
                      int32_t *status, int32_t *stats, void *stream)
 {

@@ -96,6 +96,10 @@ hipError_t launch_solve_body(int H, const SolveWorkspace &W, int bound, int roun
 hipError_t launch_solve_result(int H, const SolveWorkspace &W, int count, int slot, double *x, double *fun, int32_t *nit,
                                int32_t *status, int32_t *stats, hipStream_t stream);
 hipError_t launch_solve_count(const SolveWorkspace &W, int slot, hipStream_t stream);
+// kernels_team.hip: every problem run to its end by one workgroup at a time (no lock step), after launch_solve_begin
+bool solve_team_supported(const mpc_params &P);
+hipError_t launch_solve_team(const mpc_params &P, const double *decay, const mpc_scenarios &sc, const SolveWorkspace &W, int count,
+                             int maxiter, int teams, double *work, int *iwork, hipStream_t stream);
 hipError_t launch_ordered_sum_probe(int count, const double *terms, const double *t0, const int32_t *first, double *out,
                                     hipStream_t stream);
 // One request list of a device-resident solve: evaluate rows list[0 .. *count) of the per-problem arrays in place

@@ -28,6 +28,11 @@ from .native_solver import MODE_NEEDS_HOST, active_lanes
 from .solver import BatchSolveResult
 
 
+def p_supports_team(ctx: MpcContext) -> bool:
+    """mpc_solve_run's conditions (include/mpc_amd.h): the structured dc/dx path and a horizon of at most 21."""
+    return ctx.nz_supported() and ctx.params.horizon <= 21
+
+
 class _ResidentLane:
     def __init__(self, ctx: MpcContext, capacity: int):
         self.ctx = ctx
@@ -71,6 +76,17 @@ class _ResidentLane:
         self.batches += 1
         self.rounds += rounds
 
+    def run_to_the_end(self):
+        """Every problem to its end in one launch (mpc_solve_run: a workgroup per problem at a time, no lock step)."""
+        p = self.ctx.params
+        self._call(self.ctx._lib.mpc_solve_run, C.byref(self.scc), self.ws.data_ptr(), self.cap, self.ws_bytes, int(p.maxiter),
+                   self.left.data_ptr(), C.c_void_p(self.stream.cuda_stream))
+        self.events[0].record(self.stream)
+        self.events[0].synchronize()
+        if int(self.left[0]) != 0:
+            raise RuntimeError(f"mpc_solve_run gave up on {int(self.left[0])} problems (bound on calls of the body)")
+        self.running = False
+
     def check(self):
         """Wait for the batch before the one just enqueued; its count bounds every later round's lists."""
         if self.batches < 2:
@@ -101,7 +117,10 @@ class ResidentSLSQP:
     """Same interface as the other batched drivers (``solve(ScenarioBatch, x0) -> BatchSolveResult``)."""
 
     def __init__(self, ctx: MpcContext, capacity: int = None, lanes: int = 1, min_per_lane: int = 2048,
-                 rounds_per_check: int = 6):
+                 rounds_per_check: int = 6, team_max: int = None):
+        """team_max: batches of up to that many problems are solved without the lock step (mpc_solve_run: one launch,
+        a workgroup per problem at a time; same results bit for bit), larger ones in lock-step rounds.  None: 12,288
+        where the library supports it for this horizon (H <= 21), 0: never."""
         if not ctx.nz_supported():
             raise ValueError("the driver takes dc/dx in its structured form: the context needs MPC_ALGO_PREFIX")
         if not 1 <= lanes <= 8:
@@ -116,6 +135,9 @@ class ResidentSLSQP:
         self.lanes = [_ResidentLane(c, lane_cap) for c in self._ctxs]
         self.threads = 1
         self._host_fallback = None
+        if team_max is None:
+            team_max = 12288 if p_supports_team(ctx) else 0
+        self.team_max = int(team_max)
 
     device_io = True       # solve() takes start points that are already on the device and can leave the solutions there
 
@@ -147,6 +169,10 @@ class ResidentSLSQP:
             lane.stream.wait_stream(caller)              # the scenarios were written on the caller's stream
             lane.begin(sc.slice(cuts[i], cuts[i + 1]), x0[cuts[i]:cuts[i + 1]])
         R = self.rounds_per_check
+        if N <= self.team_max:
+            for lane in lanes:
+                with torch.cuda.stream(lane.stream):
+                    lane.run_to_the_end()
         while any(lane.running for lane in lanes):
             for lane in lanes:
                 if lane.running:

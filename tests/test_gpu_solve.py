@@ -691,6 +691,37 @@ def test_resident_driver_solves_inconsistent_linearisations_on_the_device(H, N, 
     assert two.n_qp > int(one.nit.sum())              # the augmented problems were extra requests
 
 
+@pytest.mark.parametrize("H,N,bad,prev", [(3, 40, (2, 7), True), (20, 24, (), False), (20, 9, (1, 4), False), (1, 9, (0, 5), True),
+                                          (20, 700, (), False)])
+def test_solves_without_the_lock_step_equal_the_rounds(H, N, bad, prev):
+    """mpc_solve_run (one launch, a workgroup per problem at a time: body, evaluations, BFGS update + QP, Kraft's
+    augmented problem) against mpc_solve_rounds on the same batch: iterates, exit modes, iteration counts, f and the
+    request statistics bit for bit; 700 problems are more than the chip has teams (the queue is walked)."""
+    from helpers import host_scenarios
+    from mpc_amd.batch import MpcContext
+    from mpc_amd.device_solver import ResidentSLSQP
+    from mpc_amd.scenarios import to_device
+
+    mp = MpcParams.reference_yaml_defaults(horizon=H)
+    ctx = MpcContext(mp, N, 0)
+    _, hs = host_scenarios(mp, N, motion="angular", cfg_id=37, with_prev=prev, goal_jitter=0.0 if H == 20 else 0.05)
+    hs.state0[list(bad), 0] = mp.q_limit + 0.2
+    sc, _ = to_device(ctx, hs)
+    with ResidentSLSQP(ctx, team_max=0) as rounds, ResidentSLSQP(ctx, team_max=N) as team:
+        one = rounds.solve(sc, hs.x)
+        two = team.solve(sc, hs.x)
+        again = team.solve(sc.slice(0, 5), hs.x[:5])
+    assert two.rounds == 0 and one.rounds > 0
+    np.testing.assert_array_equal(two.status, one.status)
+    np.testing.assert_array_equal(two.nit, one.nit)
+    np.testing.assert_array_equal(two.x, one.x)
+    np.testing.assert_array_equal(two.fun, one.fun)
+    assert (two.n_eval, two.n_eval_fd) == (one.n_eval, one.n_eval_fd)
+    if not bad:
+        assert two.n_qp == one.n_qp                       # (deferred augmented requests are counted again in the rounds)
+    np.testing.assert_array_equal(again.x, one.x[:5])
+
+
 def test_solve_rounds_reports_a_bound_that_is_too_small_and_leaves_a_finished_solve_alone():
     """mpc_solve_rounds through the C-ABI: `bound` below the number of unfinished problems is reported as -1 (problems
     were left out of a round: the solve is void) instead of a silently short count; `bound` = 0 launches nothing and

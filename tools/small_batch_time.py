@@ -1,5 +1,5 @@
 """Dev tool: resident solves of small batches (1, 16, 256, 4096 scenarios at H = 20): seconds per solve and solves/s.
-usage: small_batch_time.py [sizes ...]"""
+usage: small_batch_time.py [sizes ...] [--rounds | --team]   (force the lock-step rounds / mpc_solve_run)"""
 import os, sys; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import time
 import numpy as np, torch
@@ -8,13 +8,15 @@ from mpc_amd.device_solver import ResidentSLSQP
 from mpc_amd.params import MpcParams
 from mpc_amd.scenarios import DeviceKinematics, make_scenarios, to_device
 
-sizes = [int(a) for a in sys.argv[1:]] or [1, 16, 256, 4096]
+args = [a for a in sys.argv[1:] if not a.startswith("--")]
+team_max = 0 if "--rounds" in sys.argv else (1 << 30 if "--team" in sys.argv else None)     # default: the driver's own choice
+sizes = [int(a) for a in args] or [1, 16, 256, 4096]
 mp = MpcParams.reference_yaml_defaults(horizon=20)
 cap = max(sizes)
 ctx = MpcContext(mp, cap, 0)
 hs = make_scenarios(mp, DeviceKinematics(ctx), cap + 64, motion="angular", cfg_id=3, goal_jitter=0.0)
 sc_all, _ = to_device(ctx, hs)
-with ResidentSLSQP(ctx, capacity=cap) as solver:
+with ResidentSLSQP(ctx, capacity=cap, team_max=team_max) as solver:
     for N in sizes:
         sc = sc_all.slice(0, N)
         x0 = hs.x[:N]
