@@ -722,6 +722,46 @@ def test_solves_without_the_lock_step_equal_the_rounds(H, N, bad, prev):
     np.testing.assert_array_equal(again.x, one.x[:5])
 
 
+def test_solve_run_argument_checks():
+    """mpc_solve_run through the C-ABI: it follows mpc_solve_begin directly (after a round it is refused: the request
+    lists are then part of the state), and a horizon whose QP vectors do not fit LDS is reported as unsupported, with
+    the driver falling back to the rounds by itself."""
+    import ctypes as C
+
+    from helpers import host_scenarios
+    from mpc_amd import _ffi
+    from mpc_amd.batch import MpcContext
+    from mpc_amd.device_solver import ResidentSLSQP, p_supports_team
+    from mpc_amd.scenarios import to_device
+
+    mp = MpcParams.reference_yaml_defaults(horizon=3)
+    N = 6
+    ctx = MpcContext(mp, N, 0)
+    lib = ctx._lib
+    _, hs = host_scenarios(mp, N, motion="linear", cfg_id=29)
+    sc, _ = to_device(ctx, hs)
+    scc = ctx._scen_c(sc)
+    nbytes = int(lib.mpc_solve_workspace_bytes(3, N))
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=ctx.device)
+    x0 = torch.as_tensor(hs.x).to(ctx.device)
+    left = torch.zeros(1, dtype=torch.int32, device=ctx.device)
+    st = C.c_void_p(torch.cuda.current_stream(ctx.device).cuda_stream)
+    run = lambda: lib.mpc_solve_run(ctx._ctx, C.byref(scc), ws.data_ptr(), N, nbytes, 50, left.data_ptr(), st)
+    assert run() == -1                                                         # MPC_ERR_INVALID_ARG: no mpc_solve_begin yet
+    _ffi.check(ctx._ctx, lib.mpc_solve_begin(ctx._ctx, C.byref(scc), x0.data_ptr(), 1e-3, 50, ws.data_ptr(), N, nbytes, st))
+    _ffi.check(ctx._ctx, lib.mpc_solve_rounds(ctx._ctx, C.byref(scc), ws.data_ptr(), N, nbytes, 1, N, left.data_ptr(), st))
+    assert run() == -1                                    # a round has run
+    _ffi.check(ctx._ctx, lib.mpc_solve_begin(ctx._ctx, C.byref(scc), x0.data_ptr(), 1e-3, 50, ws.data_ptr(), N, nbytes, st))
+    assert run() == 0
+    torch.cuda.synchronize()
+    assert int(left.item()) == 0
+    big = MpcParams.reference_yaml_defaults(horizon=32)
+    ctx32 = MpcContext(big, 4, 0)
+    assert not p_supports_team(ctx32)
+    with ResidentSLSQP(ctx32) as solver:
+        assert solver.team_max == 0
+
+
 def test_solve_rounds_reports_a_bound_that_is_too_small_and_leaves_a_finished_solve_alone():
     """mpc_solve_rounds through the C-ABI: `bound` below the number of unfinished problems is reported as -1 (problems
     were left out of a round: the solve is void) instead of a silently short count; `bound` = 0 launches nothing and
