@@ -138,7 +138,8 @@ __device__ __forceinline__ int qp_serve(const HipTeam<kLds> &T, const lsqspmd::W
         T.sync();
         md = lsqspmd::lsq<true>(T, W, H, g, c, nz, lo, hi, s_out, r, r + m);
     } else {
-        md = lsqspmd::lsq(T, W, H, g, c, nz, lo, hi, s_out, r);
+        // (a reset without an update leaves the factor of the identity: lsq's short forms for a diagonal e apply)
+        md = lsqspmd::lsq(T, W, H, g, c, nz, lo, hi, s_out, r, nullptr, (fl & 3) == 1);
     }
     T.sync();
     if (md == 1) {

@@ -999,7 +999,8 @@ template <int R, bool COOP = false, bool AUG = false>
 SPMD_HD inline void transform_rows(const Work &W, int H, const int *rows, const double *cvals, const double *nz,
                                    const double *lo, const double *hi, double *const *dst, bool store = true,
                                    double *base = nullptr,      // COOP: dst[r] = base + rows[r], base the same in every lane
-                                   bool twin = false)           // also write the twin's h (row + n, column n) of every lower-bound row
+                                   bool twin = false,           // also write the twin's h (row + n, column n) of every lower-bound row
+                                   bool no_walk = false)        // e is diagonal (lsq's unit_e): no block before a column's own is read
 {
     const int n = 6 * H, mg = 12 * (H + 1) + 2 * n + (AUG ? 2 : 0);        // mg: the distance between two columns
     RowDesc d[R];
@@ -1035,18 +1036,18 @@ SPMD_HD inline void transform_rows(const Work &W, int H, const int *rows, const 
             }
         } else {
 #if defined(__HIP_DEVICE_COMPILE__)
-            if constexpr (COOP) transform_cols_wave<MPC_QP_NB, R>(W, n, mg, H, nz, base, rows, jj, d, th, skip_to, store);
+            if constexpr (COOP) transform_cols_wave<MPC_QP_NB, R>(W, n, mg, H, nz, base, rows, jj, d, th, no_walk ? jj : skip_to, store);
             else
 #endif
-                transform_cols<MPC_QP_NB, R>(W, n, mg, H, nz, dst, jj, d, first_any, th, store);
+                transform_cols<MPC_QP_NB, R>(W, n, mg, H, nz, dst, jj, d, no_walk ? jj : first_any, th, store);
         }
     }
     for (; jj < H; ++jj) {
 #if defined(__HIP_DEVICE_COMPILE__)
-        if constexpr (COOP) transform_cols_wave<1, R>(W, n, mg, H, nz, base, rows, jj, d, th, skip_to < jj ? skip_to : jj, store);
+        if constexpr (COOP) transform_cols_wave<1, R>(W, n, mg, H, nz, base, rows, jj, d, th, (no_walk || jj < skip_to) ? jj : skip_to, store);
         else
 #endif
-            transform_cols<1, R>(W, n, mg, H, nz, dst, jj, d, first_any, th, store);
+            transform_cols<1, R>(W, n, mg, H, nz, dst, jj, d, no_walk ? jj : first_any, th, store);
     }
     if (store) {
         SPMD_UNROLL
@@ -1147,9 +1148,15 @@ __device__ __attribute__((noinline)) void transform_rows_call(const double *E, c
 // of [g h]; *delta receives the last entry of the step.  What the extra row and column of e
 // contribute to the sums of the other variables are products with exact zeros at the end of sums that are never
 // -0.0 (delta finite): those terms are left out, every other operation is the serial text's.
+//
+// unit_e: the caller knows that the factor is diagonal (every entry of l below the diagonal is +0.0: the QP of a solve's
+// first iteration and the one after each of Kraft's resets, a seventeenth of all QPs and the longest).  Every sum over
+// e's off-diagonal entries then adds products (+-0.0) to a sum that starts +0.0 and stays +0.0, so the forward
+// substitution, the walk of the row transform over the blocks before a column's own and the back substitution reduce
+// to their last operation, (x - 0.0) / e(i, i), with the bits of the long form.
 template <bool AUG = false, class Team>
 SPMD_HD int lsq(const Team &T, const Work &W, int H, const double *g, const double *cvals, const double *nz, const double *lo,
-                const double *hi, double *s, double *y, double *delta = nullptr)
+                const double *hi, double *s, double *y, double *delta = nullptr, bool unit_e = false)
 {
     static_assert(!AUG || MPC_QP_ROWS == 1, "the augmented transform is written for one row per lane");
     const int n = 6 * H, m = 12 * (H + 1), mg = m + 2 * n;
@@ -1188,9 +1195,14 @@ SPMD_HD int lsq(const Team &T, const Work &W, int H, const double *g, const doub
     //      term e(k, i) f(k), which it does in the order k = 0, 1, ... of the serial dot product; the thread that
     //      owns row k + 1 (always thread 0) finishes f(k + 1) in the same sweep.  Then negate.
     bool in_registers = false;
+    if (unit_e) {
+        PAR_FOR(T, i, 0, n) W.ff[i] = (W.xs[i] - 0.0) / W.E[EO(i)];
+        T.sync();
+        in_registers = true;
+    }
 #if defined(__HIP_DEVICE_COMPILE__)
     if constexpr (Team::kWave) {
-        if (n <= lsqwave::kMaxN) {                          // the team's first wavefront, sums in registers (lsq_wave.hpp)
+        if (!unit_e && n <= lsqwave::kMaxN) {               // the team's first wavefront, sums in registers (lsq_wave.hpp)
             if (T.tid() < 64) {
                 const bool ok = lsqwave::forward_substitute(W.E, W.xs, W.ff, W.acc, n);
                 for (int i = T.tid(); i < n; i += 64) W.acc[i] = 0.0;      // it was scratch there; the team code adds into it
@@ -1334,7 +1346,7 @@ SPMD_HD int lsq(const Team &T, const Work &W, int H, const double *g, const doub
                                                                  rows[MPC_QP_ROWS - 1], mine ? 1 : 0);
             } else
 #endif
-                transform_rows<MPC_QP_ROWS, true, AUG>(W, H, rows, cvals, nz, lo, hi, dst, mine, W.AT, true);
+                transform_rows<MPC_QP_ROWS, true, AUG>(W, H, rows, cvals, nz, lo, hi, dst, mine, W.AT, true, unit_e);
         }
     }
     if constexpr (AUG) {
@@ -1374,7 +1386,7 @@ SPMD_HD int lsq(const Team &T, const Work &W, int H, const double *g, const doub
             else {
                 const int rows[1] = {i};
                 double *const dst[1] = {W.G + i};
-                transform_rows<1, false, AUG>(W, H, rows, cvals, nz, lo, hi, dst);
+                transform_rows<1, false, AUG>(W, H, rows, cvals, nz, lo, hi, dst, true, nullptr, false, unit_e);
             }
         }
     T.sync();
@@ -1430,9 +1442,13 @@ SPMD_HD int lsq(const Team &T, const Work &W, int H, const double *g, const doub
     // first wavefront alone (up to 64 threads form the products, its first thread adds them up): what one wavefront
     // writes to LDS it reads back in program order, so no workgroup barrier separates the 2n steps; the other
     // wavefronts wait at the one barrier after the loop.
+    if (unit_e) {
+        PAR_FOR(T, i, 0, n) W.xs[i] = (W.xs[i] - 0.0) / W.E[EO(i)];
+        T.sync();
+    }
 #if defined(__HIP_DEVICE_COMPILE__)
     if constexpr (Team::kWave) {
-        if (in_registers) {                                // lsq_wave.hpp: the same chain at ~8 cycles per term
+        if (!unit_e && in_registers) {                     // lsq_wave.hpp: the same chain at ~8 cycles per term
             if (T.tid() < 64) {
                 const bool ok = lsqwave::back_substitute(W.E, W.xs, W.acc, n);
                 if (T.tid() == 0) W.isc[14] = ok ? 1 : 0;

@@ -15,6 +15,7 @@ int mpc_lsq_spmd_nnls_iterations = 0;
 // diagnostic: how many of the calls so far were Kraft's augmented problem (tests make sure the case was met)
 extern "C" {
 int mpc_lsq_spmd_augmented_calls = 0;
+int mpc_lsq_spmd_diagonal_calls = 0;      // ... and calls that took the short forms for a diagonal factor
 }
 
 extern "C" void mpc_lsq_spmd_serial(int m, int meq, int n, int nl, int la, double *l, double *g, double *a, double *b,
@@ -46,7 +47,13 @@ extern "C" void mpc_lsq_spmd_serial(int m, int meq, int n, int nl, int la, doubl
         mpc_lsq_spmd_augmented_calls++;
         *mode = lsqspmd::lsq<true>(lsqspmd::SerialTeam(), W, H, g, b, nz.data(), xl, xu, x, yy.data(), &x[nv]);
     } else {
-        *mode = lsqspmd::lsq(lsqspmd::SerialTeam(), W, H, g, b, nz.data(), xl, xu, x, yy.data());
+        // a diagonal factor (the first QP of a solve, the one after a reset) takes lsq's short forms, as on the device
+        bool diagonal = true;
+        for (int r = 0, e = 0; r < nv && diagonal; ++r)
+            for (int c = r; c < nv; ++c, ++e)
+                if (c != r && (l[e] != 0.0 || std::signbit(l[e]))) { diagonal = false; break; }
+        mpc_lsq_spmd_diagonal_calls += diagonal ? 1 : 0;
+        *mode = lsqspmd::lsq(lsqspmd::SerialTeam(), W, H, g, b, nz.data(), xl, xu, x, yy.data(), nullptr, diagonal);
     }
     mpc_lsq_spmd_nnls_iterations = W.isc[3];
     if (*mode == 1) {
@@ -109,7 +116,7 @@ extern "C" int mpc_qp_step_serial(int H, int flags, const double *lo, const doub
         W.E[ldl - 1] = rho;
         md = lsqspmd::lsq<true>(T, W, H, g, c, nz, lo, hi, s, r, r + m);
     } else {
-        md = lsqspmd::lsq(T, W, H, g, c, nz, lo, hi, s, r);
+        md = lsqspmd::lsq(T, W, H, g, c, nz, lo, hi, s, r, nullptr, (flags & 3) == 1);
     }
     if (md == 1)
         for (int i = 0; i < n; ++i) v[i] = g[i] - lsqspmd::jac_column_dot(H, nz, r, i);

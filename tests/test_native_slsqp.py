@@ -117,6 +117,8 @@ def test_team_parallel_lsq_with_a_team_of_one_keeps_whole_solves_identical(H, N,
     hs.state0[list(bad), 0] = mp.q_limit + 0.2
     aug_calls = ctypes.c_int.in_dll(lib, "mpc_lsq_spmd_augmented_calls")
     aug_before = aug_calls.value
+    diag_calls = ctypes.c_int.in_dll(lib, "mpc_lsq_spmd_diagonal_calls")       # lsq's short forms for a diagonal factor
+    diag_before = diag_calls.value
     n = mp.n
     lb = np.array([b[0] for b in mp.bounds()])
     ub = np.array([b[1] for b in mp.bounds()])
@@ -153,6 +155,7 @@ def test_team_parallel_lsq_with_a_team_of_one_keeps_whole_solves_identical(H, N,
         lib.mpc_slsqp_set_lsq(None)
         lib.mpc_slsqp_set_bfgs(None)
     assert (aug_calls.value > aug_before) == bool(bad)
+    assert diag_calls.value - diag_before >= N                 # every solve's first QP at least
     assert len(got[0]) == len(want[0])
     for (xa, ma), (xb, mb) in zip(got[0], want[0]):
         np.testing.assert_array_equal(ma, mb)

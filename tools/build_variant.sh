@@ -9,7 +9,9 @@ rm -rf "$dst"; mkdir -p "$dst/csrc" "$dst/include"
 git -C "$root" archive "$rev" mpc_amd/csrc include | tar -x -C "$dst" --strip-components=0
 src=$dst/mpc_amd/csrc
 objs=""
-for u in mpc_abi kernels_rollout kernels_aux kernels_prefix kernels_qp kernels_slsqp; do
+units="mpc_abi kernels_rollout kernels_aux kernels_prefix kernels_qp kernels_slsqp"
+[ -f "$src/kernels_team.hip" ] && units="$units kernels_team"
+for u in $units; do
   strict="-ffp-contract=off"; [ $u = mpc_abi ] && strict=""
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wno-unused-function -I"$dst/include" -I"$src" $strict "$@" -c "$src/$u.hip" -o "$dst/$u.o" &
   objs="$objs $dst/$u.o"
