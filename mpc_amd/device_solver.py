@@ -134,7 +134,6 @@ class ResidentSLSQP:
         self._ctxs = [ctx] + [MpcContext(ctx.params, lane_cap, ctx.device_index) for _ in range(lanes - 1)]
         self.lanes = [_ResidentLane(c, lane_cap) for c in self._ctxs]
         self.threads = 1
-        self._host_fallback = None
         if team_max is None:
             team_max = 12288 if p_supports_team(ctx) else 0
         self.team_max = int(team_max)
@@ -194,32 +193,17 @@ class ResidentSLSQP:
         status = np.concatenate([r[3] for r in parts])
         stats = np.sum([r[4] for r in parts], axis=0)
         n_eval, n_eval_fd, n_qp = int(stats[0]), int(stats[1]) + N, int(stats[2])
-        redo = np.nonzero(status == MODE_NEEDS_HOST)[0]      # (the device solves those too: kept for a library built without)
-        if len(redo) and x_on_device:
-            raise RuntimeError("status 104 from a device-resident solve whose solutions stay on the device")
-        if len(redo):                       # inconsistent linearisation somewhere along the way: host-only solve
-            from .native_solver import NativeBatchedSLSQP
-
-            if self._host_fallback is None:
-                self._host_fallback = NativeBatchedSLSQP(ctx, threads=0, capacity=self.cap, groups=1)
-            sub = ctx.gather(sc, torch.from_numpy(redo.astype(np.int32)).to(ctx.device),
-                             ScenarioBatch.empty(ctx.device, len(redo), p.horizon, sc.u_prev is not None))
-            r2 = self._host_fallback.solve(sub, x0[redo].cpu().numpy() if isinstance(x0, torch.Tensor) else x0[redo])
-            x[redo], fun[redo], nit[redo], status[redo] = r2.x, r2.fun, r2.nit, r2.status
-            n_eval += r2.n_eval
-            n_eval_fd += r2.n_eval_fd
+        if (status == MODE_NEEDS_HOST).any():      # the device solves Kraft's augmented problem itself: never handed back
+            raise RuntimeError("status 104 from a device-resident solve: the library and this driver are out of step")
         res = BatchSolveResult(x=x, fun=fun, nit=nit, status=status, rounds=max(lane.rounds for lane in lanes), n_eval=n_eval,
                                n_eval_fd=n_eval_fd, t_core=0.0, t_serve=time.perf_counter() - t_start)
-        res.n_qp, res.t_qp, res.n_host_fallback = n_qp, 0.0, len(redo)
+        res.n_qp, res.t_qp, res.n_host_fallback = n_qp, 0.0, 0
         res.x_dev = x_dev
         res.t_wall = time.perf_counter() - t_start
         return res
 
     def close(self):
         self.lanes = []
-        if self._host_fallback is not None:
-            self._host_fallback.close()
-            self._host_fallback = None
 
     def __enter__(self):
         return self

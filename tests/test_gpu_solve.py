@@ -722,6 +722,36 @@ def test_solves_without_the_lock_step_equal_the_rounds(H, N, bad, prev):
     np.testing.assert_array_equal(again.x, one.x[:5])
 
 
+@pytest.mark.parametrize("H,N", [(3, 300), (20, 200)])
+def test_rounds_on_a_side_stream_of_the_callers_equal_the_default_stream(H, N):
+    """mpc_solve_rounds runs a round's evaluations on a stream of the library's own beside the QPs (from 128 unfinished
+    problems on), forked from and joined to the caller's stream by events: the same batch solved on torch's default
+    stream and on another stream of the caller's gives the same bits, and work queued on the caller's stream right
+    behind the solve sees its results."""
+    from helpers import host_scenarios
+    from mpc_amd.batch import MpcContext
+    from mpc_amd.device_solver import ResidentSLSQP
+    from mpc_amd.scenarios import to_device
+
+    mp = MpcParams.reference_yaml_defaults(horizon=H)
+    ctx = MpcContext(mp, N, 0)
+    _, hs = host_scenarios(mp, N, motion="angular", cfg_id=41, goal_jitter=0.0 if H == 20 else 0.05)
+    sc, _ = to_device(ctx, hs)
+    with ResidentSLSQP(ctx, team_max=0) as solver:
+        one = solver.solve(sc, hs.x)
+        torch.cuda.synchronize()
+        side = torch.cuda.Stream(device=ctx.device)
+        with torch.cuda.stream(side):
+            two = solver.solve(sc, hs.x, x_on_device=True)
+            kept = two.x_dev.clone()                       # queued behind the solve on the same stream
+        side.synchronize()
+    assert one.rounds > 0
+    np.testing.assert_array_equal(two.status, one.status)
+    np.testing.assert_array_equal(two.nit, one.nit)
+    np.testing.assert_array_equal(two.fun, one.fun)
+    np.testing.assert_array_equal(kept.cpu().numpy(), one.x)
+
+
 def test_solve_run_argument_checks():
     """mpc_solve_run through the C-ABI: it follows mpc_solve_begin directly (after a round it is refused: the request
     lists are then part of the state), and a horizon whose QP vectors do not fit LDS is reported as unsupported, with
