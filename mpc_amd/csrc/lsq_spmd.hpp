@@ -701,6 +701,11 @@ SPMD_HD int nnls(const Team &T, const Work &W, int mrow, int ncol, int mg, doubl
 #ifndef MPC_QP_NB
 #define MPC_QP_NB 2
 #endif
+#ifndef MPC_QP_FREE_STEP
+#define MPC_QP_FREE_STEP 1         // lsq tries the unconstrained step first (0: always the long form; development)
+#endif
+constexpr double kFreeStepMargin = 1e-6;    // a row passes if its slack is at least this times the magnitude of its terms
+constexpr double kFreeStepSpread = 1e-3;    // ... and e's diagonal entries lie within 1e-3 .. 1e3 of the first
 #ifndef MPC_QP_ROWS
 #define MPC_QP_ROWS 1              // rows per lane; see lsq's row loop for why one beats two on the device
 #endif
@@ -1163,6 +1168,49 @@ SPMD_HD int lsq(const Team &T, const Work &W, int H, const double *g, const doub
     const int N = n + (AUG ? 1 : 0), ld = mg + (AUG ? 2 : 0);           // ld rows of [g h], columns ld apart
 #define EO(r) ((r) * n - ((r) * ((r) - 1)) / 2)
     QP_MARK_START(T);
+    // x = e^-1 x in place (W.xs) by back substitution: row i needs the products e(i, j) x(j), j > i, added in ascending j
+    // while x(j) becomes known in the opposite order, so the sum itself is a serial chain.  The whole recurrence runs on
+    // the team's first wavefront alone: with the vector in registers where lsq_wave.hpp applies (wave_first), else up to
+    // 64 threads form the products and the first adds them up (what one wavefront writes to LDS it reads back in program
+    // order, so no workgroup barrier separates the 2n steps; the other wavefronts wait at the one barrier after the loop).
+    auto back_substitution = [&](bool wave_first) {
+        if (unit_e) {
+            PAR_FOR(T, i, 0, n) W.xs[i] = (W.xs[i] - 0.0) / W.E[EO(i)];
+            T.sync();
+            return;
+        }
+        bool done = false;
+#if defined(__HIP_DEVICE_COMPILE__)
+        if constexpr (Team::kWave) {
+            if (wave_first) {                              // lsq_wave.hpp: the same chain at ~8 cycles per term
+                if (T.tid() < 64) {
+                    const bool ok = lsqwave::back_substitute(W.E, W.xs, W.acc, n);
+                    if (T.tid() == 0) W.isc[14] = ok ? 1 : 0;
+                }
+                T.sync();
+                done = W.isc[14] != 0;                     // false: xs is as it was, the team code below runs
+                T.sync();
+            }
+        }
+#endif
+        (void)wave_first;
+        if (!done) {
+            const int wl = T.size() < 64 ? T.size() : 64;
+            if (T.tid() < wl) {
+                for (int i = n - 1; i >= 0; --i) {
+                    const double *er = W.E + EO(i) - i;        // er[j] = e(i, j)
+                    for (int j = i + 1 + T.tid(); j < n; j += wl) W.piv[j] = er[j] * W.xs[j];
+                    T.wave_sync();
+                    if (T.tid() == 0) {
+                        const double t = sum_in_order(0.0, W.piv + i + 1, n - i - 1);
+                        W.xs[i] = (W.xs[i] - t) / er[i];
+                    }
+                    T.wave_sync();
+                }
+            }
+            T.sync();
+        }
+    };
     // ---- e = sqrt(d) l^T in place (row r of e is column r of l scaled by sqrt(d_r))
     PAR_FOR(T, i, 0, n) {
         W.piv[i] = sqrt(W.E[EO(i)]);
@@ -1293,6 +1341,67 @@ SPMD_HD int lsq(const Team &T, const Work &W, int H, const double *g, const doub
     T.sync();
     if (!W.isc[8]) return 5;
     QP_MARK(T, 2);   // QR rows
+#if MPC_QP_FREE_STEP
+    // ---- The unconstrained step first.  Four QPs in five end with an empty final set: no row of [g h] has a positive
+    //      h, NNLS leaves at its first test, and the answer is x = e^-1 f with every multiplier +0.0 - nothing of the
+    //      transformed matrix reaches the result except the signs of h, and h(j) <= 0 says that x satisfies row j of the
+    //      constraints.  So that x is computed first (the back substitution the long form would end with, on the same
+    //      operands: 0.0 + 1.0 f), and the rows are tested on it directly, G(j) x - h(j) against a margin of
+    //      kFreeStepMargin times the magnitude of the terms: where every row passes, the long form's h (the same quantity,
+    //      rounded along another path: the two differ by about cond(e) 1e-16 of that magnitude, and the diagonal's spread
+    //      is bounded here as well) is negative in every row too, and its result is this one bit for bit.  Where a row
+    //      does not pass clearly, the long form decides.
+    if constexpr (!AUG) {
+        PAR_FOR(T, i, 0, n) W.xs[i] = 0.0 + 1.0 * W.ff[i];
+        if (T.tid() == 0) W.isc[4] = 1;
+        T.sync();
+        back_substitution(in_registers);
+        const double a0 = fabs(W.E[0]);
+        PAR_FOR(T, i, 0, m + n) {
+            bool ok;
+            if (i < m) {
+                const RowDesc d = describe_row(H, i, cvals, lo, hi);
+                double v = 0.0, a = 0.0;
+                for (int jj = d.first; jj <= d.last; ++jj) {
+                    const double gv = d.kind == 1 ? nz[6 * H + 6 * (jj * H - (jj * (jj - 1)) / 2 - jj - 1 + d.kk) + d.a]
+                                                  : nz[6 * jj + d.a];
+                    const double t = gv * W.xs[6 * jj + d.a];
+                    v = v + t;
+                    a = a + fabs(t);
+                }
+                const double slack = v - d.hval;
+                ok = slack > 0.0 && slack >= kFreeStepMargin * (a + fabs(d.hval));
+            } else {
+                const int q = i - m;
+                const double x = W.xs[q], l = lo[q], u = hi[q], e = fabs(W.E[EO(q)]);
+                ok = x - l > 0.0 && x - l >= kFreeStepMargin * (fabs(x) + fabs(l)) && u - x > 0.0 &&
+                     u - x >= kFreeStepMargin * (fabs(x) + fabs(u)) && e >= kFreeStepSpread * a0 && e * kFreeStepSpread <= a0;
+            }
+            if (!ok) W.isc[4] = 0;
+        }
+        T.sync();
+#if MPC_QP_FREE_STEP == 2          // development: the long form runs all the same, and says whether the prediction held
+        if (T.tid() == 0) { W.isc[6] = W.isc[4]; W.isc[5] = 0; }
+        T.sync();
+        if (false) {
+#else
+        if (W.isc[4]) {
+#endif
+            PAR_FOR(T, i, 0, mg) y[i] = 0.0 + 1.0 * 0.0;
+            PAR_FOR(T, i, 0, n) {
+                double v = W.xs[i];
+                if (v < lo[i]) v = lo[i];
+                else if (v > hi[i]) v = hi[i];
+                s[i] = v;
+            }
+            if (T.tid() == 0) { W.isc[3] = 0; W.isc[5] = 1; }
+            T.sync();
+            QP_MARK(T, 7);   // (the free step's time goes to back substitution + box)
+            return 1;
+        }
+        if (T.tid() == 0) W.isc[5] = 0;
+    }
+#endif
     // ---- [g h] <- [g e^-1, h - g f], MPC_QP_ROWS rows per index (they share the reads of e), into the matrix NNLS
     //      works on.  Whole wavefronts walk the loop together (a lane beyond the last row repeats a row without
     //      storing), so that on the device a wavefront loads the entries of e once for all its lanes; and the rows are
@@ -1376,6 +1485,12 @@ SPMD_HD int lsq(const Team &T, const Work &W, int H, const double *g, const doub
     int mode = nnls(T, W, N + 1, ld, ld, &W.sc[2]);
     T.sync();
     rnorm = W.sc[2];
+#if MPC_QP_FREE_STEP == 2
+    if constexpr (!AUG) {
+        if (T.tid() == 0) W.isc[5] = W.isc[6] ? (mode == 1 && W.isc[11] == 0 && W.isc[3] == 0 ? 1 : 2) : 0;   // 2: predicted free, was not
+        T.sync();
+    }
+#endif
     if (mode != 1) return mode;
     if (rnorm <= 0.0) return 4;
     QP_MARK(T, 4);   // NNLS
@@ -1438,43 +1553,7 @@ SPMD_HD int lsq(const Team &T, const Work &W, int H, const double *g, const doub
         }
     }
     T.sync();
-    // Row i needs the products e(i, j) x(j), j > i, added in ascending j.  The whole recurrence runs on the team's
-    // first wavefront alone (up to 64 threads form the products, its first thread adds them up): what one wavefront
-    // writes to LDS it reads back in program order, so no workgroup barrier separates the 2n steps; the other
-    // wavefronts wait at the one barrier after the loop.
-    if (unit_e) {
-        PAR_FOR(T, i, 0, n) W.xs[i] = (W.xs[i] - 0.0) / W.E[EO(i)];
-        T.sync();
-    }
-#if defined(__HIP_DEVICE_COMPILE__)
-    if constexpr (Team::kWave) {
-        if (!unit_e && in_registers) {                     // lsq_wave.hpp: the same chain at ~8 cycles per term
-            if (T.tid() < 64) {
-                const bool ok = lsqwave::back_substitute(W.E, W.xs, W.acc, n);
-                if (T.tid() == 0) W.isc[14] = ok ? 1 : 0;
-            }
-            T.sync();
-            in_registers = W.isc[14] != 0;                  // false: xs is as it was, the team code below runs
-            T.sync();
-        }
-    }
-#endif
-    if (!in_registers) {
-        const int wl = T.size() < 64 ? T.size() : 64;
-        if (T.tid() < wl) {
-            for (int i = n - 1; i >= 0; --i) {
-                const double *er = W.E + EO(i) - i;        // er[j] = e(i, j)
-                for (int j = i + 1 + T.tid(); j < n; j += wl) W.piv[j] = er[j] * W.xs[j];
-                T.wave_sync();
-                if (T.tid() == 0) {
-                    const double t = sum_in_order(0.0, W.piv + i + 1, n - i - 1);
-                    W.xs[i] = (W.xs[i] - t) / er[i];
-                }
-                T.wave_sync();
-            }
-        }
-        T.sync();
-    }
+    back_substitution(in_registers);
     PAR_FOR(T, i, 0, n) {
         double v = W.xs[i];
         if (v < lo[i]) v = lo[i];

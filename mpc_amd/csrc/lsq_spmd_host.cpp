@@ -15,6 +15,9 @@ int mpc_lsq_spmd_nnls_iterations = 0;
 // diagnostic: how many of the calls so far were Kraft's augmented problem (tests make sure the case was met)
 extern "C" {
 int mpc_lsq_spmd_augmented_calls = 0;
+int mpc_lsq_spmd_free_steps = 0;          // ... calls that ended with the unconstrained step (lsq's MPC_QP_FREE_STEP)
+int mpc_lsq_spmd_free_step_errors = 0;   // ... (a build with MPC_QP_FREE_STEP=2) predictions that did not hold
+int mpc_lsq_spmd_plain_calls = 0;         // ... of so many calls of the plain problem
 int mpc_lsq_spmd_diagonal_calls = 0;      // ... and calls that took the short forms for a diagonal factor
 }
 
@@ -53,7 +56,11 @@ extern "C" void mpc_lsq_spmd_serial(int m, int meq, int n, int nl, int la, doubl
             for (int c = r; c < nv; ++c, ++e)
                 if (c != r && (l[e] != 0.0 || std::signbit(l[e]))) { diagonal = false; break; }
         mpc_lsq_spmd_diagonal_calls += diagonal ? 1 : 0;
+        W.isc[5] = 0;
         *mode = lsqspmd::lsq(lsqspmd::SerialTeam(), W, H, g, b, nz.data(), xl, xu, x, yy.data(), nullptr, diagonal);
+        mpc_lsq_spmd_plain_calls++;
+        mpc_lsq_spmd_free_steps += W.isc[5] ? 1 : 0;
+        mpc_lsq_spmd_free_step_errors += W.isc[5] == 2 ? 1 : 0;
     }
     mpc_lsq_spmd_nnls_iterations = W.isc[3];
     if (*mode == 1) {
@@ -116,7 +123,11 @@ extern "C" int mpc_qp_step_serial(int H, int flags, const double *lo, const doub
         W.E[ldl - 1] = rho;
         md = lsqspmd::lsq<true>(T, W, H, g, c, nz, lo, hi, s, r, r + m);
     } else {
+        W.isc[5] = 0;
         md = lsqspmd::lsq(T, W, H, g, c, nz, lo, hi, s, r, nullptr, (flags & 3) == 1);
+        mpc_lsq_spmd_plain_calls++;
+        mpc_lsq_spmd_free_steps += W.isc[5] ? 1 : 0;
+        mpc_lsq_spmd_free_step_errors += W.isc[5] == 2 ? 1 : 0;
     }
     if (md == 1)
         for (int i = 0; i < n; ++i) v[i] = g[i] - lsqspmd::jac_column_dot(H, nz, r, i);

@@ -1,5 +1,7 @@
 """Time whole batched solves: ResidentSLSQP (everything on the device) beside DeviceQpSLSQP (host threads keep
-SLSQP's scalar logic).  usage: resident_time.py N1,N2,... [lanes] [rounds_per_check] [--no-devqp]"""
+SLSQP's scalar logic).  usage: resident_time.py N1,N2,... [lanes] [rounds_per_check] [--no-devqp] [--hash]
+--hash: also print a SHA-256 over the solutions, f, iteration counts and exit modes (two builds of the library that print
+the same hash solved every problem with the same bits)"""
 import os, sys; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import time
 import numpy as np
@@ -34,6 +36,12 @@ def main():
             dt = time.perf_counter() - t0
         print(f"resident N={M} lanes={len(dev.lanes) if dev.lanes else lanes} rpc={rpc}: {dt:.3f}s -> {M/dt:.0f} solves/s; rounds={r.rounds} "
               f"qps={r.n_qp} nf={r.n_eval} nfd={r.n_eval_fd} conv={int(r.success.sum())} fallback={r.n_host_fallback}", flush=True)
+        if "--hash" in sys.argv:
+            import hashlib
+            h = hashlib.sha256()
+            for a in (r.x, r.fun, r.nit.astype(np.int64), r.status.astype(np.int64)):
+                h.update(np.ascontiguousarray(a).tobytes())
+            print(f"hash N={M}: {h.hexdigest()} nit sum {int(r.nit.sum())}", flush=True)
         if "--no-devqp" not in sys.argv:
             with DeviceQpSLSQP(ctx, threads=15, capacity=M) as dq:
                 dq.solve(sc.slice(0, 8), x0[:8])
