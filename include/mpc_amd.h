@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MPC_AMD_ABI_VERSION 10
+#define MPC_AMD_ABI_VERSION 11
 #define MPC_MAX_HORIZON 255
 
 typedef enum mpc_status {
@@ -259,7 +259,9 @@ int mpc_qp_step(mpc_ctx *ctx, int count, int rows, const int32_t *index, const i
  *       the rounds launch from the first call on that finds the flag up which the QP kernel raises (a word of
  *       pinned host memory) when it meets one; until then the problem waits, asking again every round.
  *   mpc_solve_result: x [N][n], fun [N], nit [N], status [N] (SLSQP's exit mode, 0 = converged) and, if non-NULL,
- *       stats[4] = {mpc_eval requests, mpc_eval_fd_nz requests, QP steps, unfinished in the last round} (device).
+ *       stats[5] = {mpc_eval requests, mpc_eval_fd_nz requests, QP steps, unfinished in the last round, QP steps that
+ *       ended with the unconstrained step (no constraint near: the QP kernel skips the transformed matrix and NNLS)}
+ *       (device).
  * `sc` must be the same batch in all three calls; calls on one context / one workspace must not overlap. */
 size_t mpc_solve_workspace_bytes(int horizon, int rows);
 int mpc_solve_begin(mpc_ctx *ctx, const mpc_scenarios *sc, const double *x0, double acc, int maxiter, void *ws, int rows,

@@ -11,7 +11,7 @@ LIB_PATH = os.environ.get("MPC_AMD_LIB") or os.path.join(_HERE, "libmpc_amd.so")
 MPC_OK = 0
 ALGO_AUTO, ALGO_ROLLOUT, ALGO_PREFIX = 0, 1, 2
 MAX_HORIZON = 255
-ABI_VERSION = 10
+ABI_VERSION = 11
 STATIC_SCRATCH_DOUBLES = 2 * 1024 * 1024
 
 EXPORTS = (

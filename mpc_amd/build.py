@@ -11,6 +11,9 @@ _ROOT = os.path.dirname(_HERE)
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(_HERE, "libmpc_amd.so")
 SLSQP_LIB_PATH = os.path.join(_HERE, "libmpc_slsqp.so")     # host-only: the native batched SLSQP driver
+# the same with lsq's free step in its checking form (-DMPC_QP_FREE_STEP=2: the long form runs all the same and the
+# library counts predictions that did not hold); tests/test_native_slsqp.py loads it through MPC_SLSQP_LIB
+SLSQP_CHECK_LIB_PATH = os.path.join(_HERE, "libmpc_slsqp_check.so")
 _SLSQP_UNITS = ["slsqp_core.c", "slsqp_batch.c"]
 # one rounding per operation: with it the C core reproduces scipy's compiled core bit for bit
 _SLSQP_FLAGS = ["-O3", "-ffp-contract=off", "-fPIC", "-fopenmp", "-Wall", "-std=gnu11"]
@@ -78,7 +81,7 @@ def build_slsqp(force: bool = False, verbose: bool = False) -> str:
     deps = srcs + [os.path.join(CSRC, "slsqp_core.h"), os.path.join(CSRC, "slsqp_body.inc"),
                    os.path.join(_ROOT, "include", "mpc_slsqp.h")]
     spmd = [os.path.join(CSRC, "lsq_spmd_host.cpp"), os.path.join(CSRC, "lsq_spmd.hpp"), os.path.join(CSRC, "lsq_wave.hpp")]
-    if force or _stale(SLSQP_LIB_PATH, deps + spmd):
+    if force or _stale(SLSQP_LIB_PATH, deps + spmd) or _stale(SLSQP_CHECK_LIB_PATH, deps + spmd):
         objdir = os.path.join(_HERE, "build")
         os.makedirs(objdir, exist_ok=True)
         inc = ["-I" + os.path.join(_ROOT, "include"), "-I" + CSRC]
@@ -91,6 +94,10 @@ def build_slsqp(force: bool = False, verbose: bool = False) -> str:
             c_objs.append(obj)
             cmds.append([gcc] + _SLSQP_FLAGS + inc + ["-c", src, "-o", obj])
         cmds.append([gxx, "-shared", "-fopenmp", "-o", SLSQP_LIB_PATH] + c_objs + [spmd_obj, "-lm"])
+        check_obj = os.path.join(objdir, "lsq_spmd_host_check.o")
+        cmds.append([gxx, "-O2", "-ffp-contract=off", "-fPIC", "-std=c++17", "-Wall", "-DMPC_QP_FREE_STEP=2"] + inc +
+                    ["-c", spmd[0], "-o", check_obj])
+        cmds.append([gxx, "-shared", "-fopenmp", "-o", SLSQP_CHECK_LIB_PATH] + c_objs + [check_obj, "-lm"])
         for cmd in cmds:
             if verbose:
                 print(" ".join(cmd), flush=True)

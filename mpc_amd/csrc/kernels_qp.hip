@@ -172,7 +172,7 @@ qp_step_kernel(int H, int count, int rows, const int32_t *__restrict__ index, co
                const int32_t *__restrict__ flags, const double *__restrict__ lo, const double *__restrict__ hi, const double *s_in,
                double *L, const double *__restrict__ G, const double *__restrict__ C, const double *__restrict__ NZ, double *R,
                double *V, double *s_out, double *__restrict__ r_out, int32_t *__restrict__ mode, int32_t *head, double *work,
-               int *iwork, size_t wd, size_t wi, int32_t *aug_seen)
+               int *iwork, size_t wd, size_t wi, int32_t *aug_seen, int32_t *free_steps)
 {
     const int n = 6 * H, m = 12 * (H + 1), mg = m + 2 * n, nzc = 6 * H + 3 * H * (H + 1);
     const int ldl = (n + 1) * n / 2 + 1;
@@ -207,7 +207,9 @@ qp_step_kernel(int H, int count, int rows, const int32_t *__restrict__ index, co
             }
             continue;
         }
+        if (threadIdx.x == 0) W.isc[5] = 0;
         const int md = qp_serve<kLds, kAug>(T, W, H, fl, l, g, c, nz, r, v, lo + q * n, hi + q * n, s_in + q * n, s_out + q * n);
+        if (free_steps && threadIdx.x == 0 && W.isc[5] == 1) atomicAdd(free_steps, 1);     // (lsq: the unconstrained step sufficed)
         if (md == 1 && !kRows) PAR_FOR(T, i, 0, m) r_out[q * m + i] = r[i];
         if (threadIdx.x == 0) mode[q] = md;
         __syncthreads();
@@ -260,7 +262,8 @@ template <bool kRows, bool kAug>
 hipError_t launch_qp_step_any(int H, int count, int teams, int rows, const int32_t *index, const int32_t *count_dev,
                               const int32_t *flags, const double *lo, const double *hi, const double *s_in, double *L, const double *G,
                               const double *C, const double *NZ, double *R, double *V, double *s_out, double *r_out, int32_t *mode,
-                              int32_t *head, double *work, int *iwork, int32_t *aug_seen, hipStream_t stream)
+                              int32_t *head, double *work, int *iwork, int32_t *aug_seen, int32_t *free_steps,
+                              hipStream_t stream)
 {
     const size_t lds = lds_bytes(H, kAug ? 1 : 0);
     if (lds) {
@@ -269,11 +272,11 @@ hipError_t launch_qp_step_any(int H, int count, int teams, int rows, const int32
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL((qp_step_kernel<true, kRows, kAug>), dim3((unsigned)teams), dim3(kQpThreads), lds, stream, H, count, rows,
                            index, count_dev, flags, lo, hi, s_in, L, G, C, NZ, R, V, s_out, r_out, mode, head, work, iwork,
-                           qp_work_doubles(H), qp_work_ints(H), aug_seen);
+                           qp_work_doubles(H), qp_work_ints(H), aug_seen, free_steps);
     } else {
         hipLaunchKernelGGL((qp_step_kernel<false, kRows, kAug>), dim3((unsigned)teams), dim3(kQpThreads), 0, stream, H, count, rows,
                            index, count_dev, flags, lo, hi, s_in, L, G, C, NZ, R, V, s_out, r_out, mode, head, work, iwork,
-                           qp_work_doubles(H), qp_work_ints(H), aug_seen);
+                           qp_work_doubles(H), qp_work_ints(H), aug_seen, free_steps);
     }
     return hipGetLastError();
 }
@@ -285,22 +288,22 @@ hipError_t launch_qp_step(int H, int count, int teams, int rows, const int32_t *
                           hipStream_t stream)
 {
     return launch_qp_step_any<false, false>(H, count, teams, rows, index, nullptr, flags, lo, hi, s_in, L, G, C, NZ, R, V, s_out,
-                                            r_out, mode, nullptr, work, iwork, nullptr, stream);
+                                            r_out, mode, nullptr, work, iwork, nullptr, nullptr, stream);
 }
 
 hipError_t launch_qp_step_rows(int H, int teams, int rows, const RowList &list, const int32_t *flags, const double *lo,
                                const double *hi, double *S, double *L, const double *G, const double *C, const double *NZ,
                                double *R, double *V, int32_t *mode, double *work, int *iwork, int32_t *aug_seen, bool augmented,
-                               hipStream_t stream)
+                               int32_t *free_steps, hipStream_t stream)
 {
     if (list.bound <= 0) return hipSuccess;
     if (list.head == nullptr) return hipErrorInvalidValue;
     const int t = teams < list.bound ? teams : list.bound;
     if (augmented)
         return launch_qp_step_any<true, true>(H, list.bound, t, rows, list.list, list.count, flags, lo, hi, S, L, G, C, NZ, R, V, S,
-                                              nullptr, mode, list.head, work, iwork, nullptr, stream);
+                                              nullptr, mode, list.head, work, iwork, nullptr, nullptr, stream);
     return launch_qp_step_any<true, false>(H, list.bound, t, rows, list.list, list.count, flags, lo, hi, S, L, G, C, NZ, R, V, S,
-                                           nullptr, mode, list.head, work, iwork, aug_seen, stream);
+                                           nullptr, mode, list.head, work, iwork, aug_seen, free_steps, stream);
 }
 
 // (sized for the augmented problem's layout, the larger of the two)

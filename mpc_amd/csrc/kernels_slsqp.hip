@@ -394,9 +394,10 @@ __global__ void solve_result_kernel(int H, SolveWorkspace W, int count, int slot
 {
     const int n = 6 * H;
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx < 4 && stats != nullptr) {     // the latest slot's requests have been served but not yet added to the totals
+    if (idx < 5 && stats != nullptr) {     // the latest slot's requests have been served but not yet added to the totals
         const int32_t *c = W.counters + 8 * slot;
-        stats[idx] = idx < 3 ? W.counters[kTotals + idx] + c[idx] : (W.counters[kOverflow] ? -1 : c[0] + c[1] + c[2]);
+        stats[idx] = idx < 3 ? W.counters[kTotals + idx] + c[idx]
+                             : (idx == 4 ? W.counters[mpck::kSolveFreeSteps] : (W.counters[kOverflow] ? -1 : c[0] + c[1] + c[2]));
     }
     if (idx >= (size_t)count * n) return;
     x[idx] = W.X[idx];

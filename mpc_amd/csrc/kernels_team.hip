@@ -27,7 +27,7 @@ namespace {
 template <bool kAug>
 __device__ __attribute__((noinline)) int qp_serve_call(double *work, int *iwork, size_t wd, size_t wi, int H, int fl, double *l,
                                                        const double *g, const double *c, const double *nz, double *r, double *v,
-                                                       const double *lo, const double *hi, double *s)
+                                                       const double *lo, const double *hi, double *s, int32_t *free_steps)
 {
     using lsqspmd::global_again;
     H = __builtin_amdgcn_readfirstlane(H);
@@ -38,8 +38,11 @@ __device__ __attribute__((noinline)) int qp_serve_call(double *work, int *iwork,
     iwork = (int *)global_again((const double *)iwork);
     const lsqspmd::Work W = team_work<true>(work, iwork, wd, wi, 6 * H, 12 * (H + 1), kAug ? 1 : 0);
     s = global_again(s);
-    return qp_serve<true, kAug>(HipTeam<true>(), W, H, fl, global_again(l), global_again(g), global_again(c), global_again(nz),
-                                global_again(r), global_again(v), global_again(lo), global_again(hi), s, s);
+    if (threadIdx.x == 0) W.isc[5] = 0;
+    const int md = qp_serve<true, kAug>(HipTeam<true>(), W, H, fl, global_again(l), global_again(g), global_again(c),
+                                        global_again(nz), global_again(r), global_again(v), global_again(lo), global_again(hi), s, s);
+    if (threadIdx.x == 0 && W.isc[5] == 1) atomicAdd(free_steps, 1);
+    return md;
 }
 #endif
 
@@ -100,8 +103,9 @@ solve_team_kernel(const mpc_params P, PrefixArgs A, SolveWorkspace W, int count,
                 int md;
                 __syncthreads();                                   // (everyone has read the flags before the QP's LDS is written)
                 if (fl & MPC_QP_FLAG_AUG) md = qp_serve_call<true>(work, iwork, wd, wi, H, fl, l, g, c, nz, r, v, W.LO + pp * n,
-                                                                   W.HI + pp * n, s);
-                else md = qp_serve_call<false>(work, iwork, wd, wi, H, fl, l, g, c, nz, r, v, W.LO + pp * n, W.HI + pp * n, s);
+                                                                   W.HI + pp * n, s, W.counters + mpck::kSolveFreeSteps);
+                else md = qp_serve_call<false>(work, iwork, wd, wi, H, fl, l, g, c, nz, r, v, W.LO + pp * n, W.HI + pp * n, s,
+                                               W.counters + mpck::kSolveFreeSteps);
                 if (tid == 0) W.QPMODE[p] = md;
                 n_q += 1;
             }

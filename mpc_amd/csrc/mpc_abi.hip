@@ -631,12 +631,13 @@ int mpc_solve_rounds(mpc_ctx *ctx, const mpc_scenarios *sc, void *ws, int rows, 
         if (beside) MPC_SOLVE_HIP(hipEventRecord(ctx->solve_joined[round & 1], ev));
         // BFGS update + QP of the problems that start a major iteration
         MPC_SOLVE_HIP(mpck::launch_qp_step_rows(ctx->horizon, ctx->qp_teams, rows, lq, W.QPFLAGS, W.LO, W.HI, W.S, W.L, W.G, W.C,
-                                                W.NZ, W.RM, W.V, W.QPMODE, ctx->d_qp_work, ctx->d_qp_iwork, ctx->aug_seen, false, st));
+                                                W.NZ, W.RM, W.V, W.QPMODE, ctx->d_qp_work, ctx->d_qp_iwork, ctx->aug_seen, false,
+                                                W.counters + mpck::kSolveFreeSteps, st));
         if (augmented) {                                    // ... and Kraft's augmented problems, where there are any
             lq.head = W.counters + 8 * cs + 5;
             MPC_SOLVE_HIP(mpck::launch_qp_step_rows(ctx->horizon, ctx->qp_teams, rows, lq, W.QPFLAGS, W.LO, W.HI, W.S, W.L, W.G,
                                                     W.C, W.NZ, W.RM, W.V, W.QPMODE, ctx->d_qp_work, ctx->d_qp_iwork, nullptr, true,
-                                                    st));
+                                                    nullptr, st));
         }
         if (beside) MPC_SOLVE_HIP(hipStreamWaitEvent(st, ctx->solve_joined[round & 1], 0));
     }

@@ -118,7 +118,8 @@ hipError_t launch_prefix_rows(const mpc_params &P, const double *decay, const mp
 hipError_t launch_qp_step_rows(int H, int teams, int rows, const RowList &list, const int32_t *flags, const double *lo,
                                const double *hi, double *S, double *L, const double *G, const double *C, const double *NZ,
                                double *R, double *V, int32_t *mode, double *work, int *iwork, int32_t *aug_seen, bool augmented,
-                               hipStream_t stream);
+                               int32_t *free_steps, hipStream_t stream);
+constexpr int kSolveFreeSteps = 29;    // place in a solve workspace's counters: QPs that ended with lsq's free step
 
 // dst row i = src row index[i] for every scenario array (NaN rows for an index outside [0, src.count))
 hipError_t launch_gather_scenarios(int H, const mpc_scenarios &src, const int32_t *index, int count,

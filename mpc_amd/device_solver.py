@@ -46,7 +46,7 @@ class _ResidentLane:
         self.fun = torch.empty(cap, dtype=torch.float64, device=dev)
         self.nit = torch.empty(cap, dtype=torch.int32, device=dev)
         self.status = torch.empty(cap, dtype=torch.int32, device=dev)
-        self.stats = torch.zeros(4, dtype=torch.int32, device=dev)
+        self.stats = torch.zeros(5, dtype=torch.int32, device=dev)
         self.left = torch.zeros(2, dtype=torch.int32).pin_memory()      # "unfinished" of the two batches in flight
         self.events = [torch.cuda.Event(), torch.cuda.Event()]
         self.stream = torch.cuda.Stream(device=dev)
@@ -198,6 +198,7 @@ class ResidentSLSQP:
         res = BatchSolveResult(x=x, fun=fun, nit=nit, status=status, rounds=max(lane.rounds for lane in lanes), n_eval=n_eval,
                                n_eval_fd=n_eval_fd, t_core=0.0, t_serve=time.perf_counter() - t_start)
         res.n_qp, res.t_qp, res.n_host_fallback = n_qp, 0.0, 0
+        res.n_free_steps = int(stats[4])       # QPs whose unconstrained step sufficed (lsq's free step)
         res.x_dev = x_dev
         res.t_wall = time.perf_counter() - t_start
         return res

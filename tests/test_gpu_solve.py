@@ -719,6 +719,8 @@ def test_solves_without_the_lock_step_equal_the_rounds(H, N, bad, prev):
     assert (two.n_eval, two.n_eval_fd) == (one.n_eval, one.n_eval_fd)
     if not bad:
         assert two.n_qp == one.n_qp                       # (deferred augmented requests are counted again in the rounds)
+    # most QPs end with lsq's free step (the unconstrained step satisfies every row with a margin), on both paths alike
+    assert two.n_free_steps == one.n_free_steps and one.n_free_steps > (0 if bad else 0.5 * one.nit.sum())
     np.testing.assert_array_equal(again.x, one.x[:5])
 
 

@@ -164,7 +164,10 @@ def test_full_size_solves_65536_angular():
     np.testing.assert_array_equal(whole.status, full.status)
     np.testing.assert_array_equal(whole.fun, full.fun)
     assert (whole.n_eval, whole.n_eval_fd, whole.n_qp) == (full.n_eval, full.n_eval_fd, full.n_qp)
-    sample = np.arange(0, len(keep), 997)
+    # five QPs in six end with lsq's free step (no transformed matrix, no NNLS): the rows below, solved by the host core
+    # (Kraft's LSQ as scipy has it, no such shortcut), say that those steps are the long form's bit for bit
+    assert whole.n_free_steps > 0.7 * whole.n_qp
+    sample = np.arange(0, len(keep), 251)
     with NativeBatchedSLSQP(ctx, threads=12, capacity=len(sample)) as host:
         want = host.solve(gather(keep[sample]), x0[keep[sample]])
     np.testing.assert_array_equal(full.x[sample], want.x)
