@@ -458,6 +458,10 @@ def solve_rate(ctx, mp, sample, threads, rank, world, dist, driver="resident", s
     if device_qp:
         out["rank0_qp_subproblems_on_gpu"] = int(r.n_qp)
         out["rank0_solved_again_on_host"] = int(r.n_host_fallback)
+    if driver == "resident" and getattr(r, "n_free_steps", None) is not None and r.n_qp:
+        # QP subproblems whose unconstrained step satisfied every constraint row with a margin (lsq's free step: no
+        # transformed matrix, no NNLS; same bits as the long form)
+        out["rank0_qp_free_step_share"] = float(r.n_free_steps) / float(r.n_qp)
     return out
 
 

@@ -3,7 +3,10 @@
    executed_fp64.json  FP64 operations the kernel EXECUTED per launch = 64 x (ADD + MUL + 2 FMA + TRANS) wavefront instructions
    qp_roofline.json    (--qp summary.txt:H:QPs per launch:kernel_stats.csv) the same two figures per QP step of the solver's
                        dominant kernel, its lane occupancy, and its share of the GPU time of a full-size solve
-usage: profiles_json.py <profiles/rNN> [--qp pmc_summary_qp.txt:H:K:kernel_stats_solve.csv]
+usage: profiles_json.py <profiles/rNN> [--qp pmc_summary_qp.txt:H:K:kernel_stats_solve.csv[:kernel_trace_solve.csv]]
+                        (with the trace: the share is the time some QP kernel was running / the span of the last solve in it,
+                         from its solve_begin_kernel to its last kernel's end - a round's evaluation kernels run beside its QP
+                         kernel on a second stream and wait there for room, so their summed durations say nothing)
                         summary.txt:variant:H:N[:kernel-substring[:dispatches per launch]] ..."""
 import json, os, re, sys
 
@@ -23,7 +26,9 @@ def parse(path):
 def qp_roofline(dst, spec):
     """pmc_qp.sh's flat summary (one kernel) + the kernel trace of a full-size resident solve -> qp_roofline.json"""
     import csv
-    path, H, K, stats = spec.split(":")
+    parts = spec.split(":")
+    path, H, K, stats = parts[:4]
+    trace = parts[4] if len(parts) > 4 else None
     c = {}
     for line in open(path):
         m = re.match(r"(\S+)\s+n=(\d+) mean=(\S+)", line)
@@ -47,6 +52,25 @@ def qp_roofline(dst, spec):
            "share_source": os.path.basename(stats), "source": os.path.basename(path),
            "note": "counters over K recorded QP subproblems of real solves (tools/qp_time.py); the share is the kernel's part of "
                    "the summed kernel time of one 65,536-scenario resident solve (rocprofv3 --kernel-trace --stats)"}
+    if trace:
+        k = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in csv.DictReader(open(trace)))
+        i0 = max(i for i, (_, _, n) in enumerate(k) if "solve_begin_kernel" in n)
+        s0, e1 = k[i0][0], max(e for _, e, _ in k[i0:])
+        busy, cs, ce = 0, None, None
+        for s_, e_, n in k[i0:]:
+            if "qp_step_kernel" not in n:
+                continue
+            if ce is None or s_ > ce:
+                busy += (ce - cs) if ce is not None else 0
+                cs, ce = s_, e_
+            else:
+                ce = max(ce, e_)
+        busy += (ce - cs) if ce is not None else 0
+        out.update({"share_of_gpu_time": busy / (e1 - s0), "solve_span_ms": (e1 - s0) / 1e6, "qp_kernel_running_ms": busy / 1e6,
+                    "share_source": os.path.basename(trace),
+                    "note": "counters over K recorded QP subproblems of real solves (tools/qp_time.py); the share is the time a QP "
+                            "kernel was running / the span of one 65,536-scenario resident solve in rocprofv3's kernel trace "
+                            "(the evaluation kernels of a round run beside its QP kernel on a second stream)"})
     json.dump(out, open(os.path.join(dst, "qp_roofline.json"), "w"), indent=1)
     print(f"qp_roofline.json: {out['executed_flops_per_qp'] / 1e6:.2f} Mflop and {out['traffic_bytes_per_qp'] / 1e6:.2f} MB per QP, "
           f"share {out['share_of_gpu_time']:.3f}")
