@@ -13,6 +13,9 @@
 #ifndef MPC_QP_ROT
 #define MPC_QP_ROT 0
 #endif
+#ifndef MPC_QP_CHAIN_ROT
+#define MPC_QP_CHAIN_ROT 1       // 0: every team runs its recurrences on its first wavefront (development)
+#endif
 #ifndef MPC_QP_WAVES
 #define MPC_QP_WAVES 2
 #endif
@@ -33,6 +36,18 @@ struct HipTeam {
     __device__ int turn() const { return (blockIdx.x & 1u) ? 2 : 0; }
 #else
     __device__ int turn() const { return 0; }
+#endif
+    // The lane number of a thread of the wavefront that runs the serial recurrences (lsq_wave.hpp), -1 for every other
+    // thread.  The two teams of a CU should not run theirs on the same SIMD: the second half of the grid (the teams that
+    // arrive on a CU second) uses its third wavefront.
+#if MPC_QP_CHAIN_ROT
+    __device__ int chain_lane() const
+    {
+        const int w = (blockIdx.x >= gridDim.x / 2) ? 2 : 0;
+        return (int)(threadIdx.x >> 6) == w ? (int)(threadIdx.x & 63u) : -1;
+    }
+#else
+    __device__ int chain_lane() const { return threadIdx.x < 64u ? (int)threadIdx.x : -1; }
 #endif
     __device__ void sync() const { __syncthreads(); }
     // orders the LDS traffic of ONE wavefront (threads 0..63 of the team): its earlier writes are done before its later

@@ -67,6 +67,7 @@ struct SerialTeam {
     SPMD_HD int tid() const { return 0; }
     SPMD_HD int size() const { return 1; }
     SPMD_HD int turn() const { return 0; }
+    SPMD_HD int chain_lane() const { return 0; }
     SPMD_HD void sync() const {}
     SPMD_HD void wave_sync() const {}
 };
@@ -1183,9 +1184,9 @@ SPMD_HD int lsq(const Team &T, const Work &W, int H, const double *g, const doub
 #if defined(__HIP_DEVICE_COMPILE__)
         if constexpr (Team::kWave) {
             if (wave_first) {                              // lsq_wave.hpp: the same chain at ~8 cycles per term
-                if (T.tid() < 64) {
+                if (const int cl = T.chain_lane(); cl >= 0) {
                     const bool ok = lsqwave::back_substitute(W.E, W.xs, W.acc, n);
-                    if (T.tid() == 0) W.isc[14] = ok ? 1 : 0;
+                    if (cl == 0) W.isc[14] = ok ? 1 : 0;
                 }
                 T.sync();
                 done = W.isc[14] != 0;                     // false: xs is as it was, the team code below runs
@@ -1251,10 +1252,10 @@ SPMD_HD int lsq(const Team &T, const Work &W, int H, const double *g, const doub
 #if defined(__HIP_DEVICE_COMPILE__)
     if constexpr (Team::kWave) {
         if (!unit_e && n <= lsqwave::kMaxN) {               // the team's first wavefront, sums in registers (lsq_wave.hpp)
-            if (T.tid() < 64) {
+            if (const int cl = T.chain_lane(); cl >= 0) {
                 const bool ok = lsqwave::forward_substitute(W.E, W.xs, W.ff, W.acc, n);
-                for (int i = T.tid(); i < n; i += 64) W.acc[i] = 0.0;      // it was scratch there; the team code adds into it
-                if (T.tid() == 0) W.isc[14] = ok ? 1 : 0;
+                for (int i = cl; i < n; i += 64) W.acc[i] = 0.0;           // it was scratch there; the team code adds into it
+                if (cl == 0) W.isc[14] = ok ? 1 : 0;
             }
             T.sync();
             in_registers = W.isc[14] != 0;                  // false: an operand out of the routine's range, ff not valid
@@ -1636,7 +1637,7 @@ SPMD_HD void ldl(const Team &T, const Work &W, int n, double *a, double *z, doub
     if constexpr (Team::kWave) {
         if (n <= lsqwave::kMaxN) {                          // the team's first wavefront, v in registers (lsq_wave.hpp)
             in_registers = true;
-            if (T.tid() < 64) lsqwave::unit_lower_solve(a, z, vv, n);
+            if (T.chain_lane() >= 0) lsqwave::unit_lower_solve(a, z, vv, n);
             T.sync();
         }
     }
