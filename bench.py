@@ -401,7 +401,10 @@ def solve_rate(ctx, mp, sample, threads, rank, world, dist, driver="resident", s
         else:
             native = (DeviceQpSLSQP if driver == "device_qp" else NativeBatchedSLSQP)(ctx, threads=threads, capacity=count)
         log("solver up")
-        warm = min(count, 32)
+        # untimed warm-up: the resident driver takes a whole tick of the same size (the timed tick below then finds torch's
+        # caching allocator holding its 0.4 GB of buffers, as every tick after a farm's first does; a fresh BatchedMPC
+        # makes it a cold start again: no warm starts, the same solves), the host-bound drivers a small one
+        warm = count if driver == "resident" else min(count, 32)
         prep = "resident" if driver == "resident" else "host"    # resident: start points and solutions never leave the device
         BatchedMPC(ctx, solver=native, prep=prep).compute_control(hs.q0[:warm], hs.state0[:warm, 12:18], hs.target[:warm],
                                                                   hs.base[:warm])
