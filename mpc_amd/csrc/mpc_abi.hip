@@ -598,6 +598,7 @@ int mpc_solve_rounds(mpc_ctx *ctx, const mpc_scenarios *sc, void *ws, int rows, 
         hipError_t e_ = (call);                                  \
         if (e_ != hipSuccess) {                                  \
             ctx->solve_ws = nullptr;                             \
+            if (ctx->solve_side) (void)hipStreamSynchronize(ctx->solve_side);   /* nothing of ours is left running */ \
             return hip_fail(ctx, e_, #call);                     \
         }                                                        \
     } while (0)

@@ -164,14 +164,15 @@ def test_team_parallel_lsq_with_a_team_of_one_keeps_whole_solves_identical(H, N,
     np.testing.assert_array_equal(got[2], want[2])
 
 
-@pytest.mark.parametrize("H,N,motion,bad", [(20, 5, "angular", ()), (3, 60, "angular", (2, 5)), (3, 60, "linear", ()),
-                                            (1, 80, "angular", (0, 3))])
-def test_free_step_predictions_hold(H, N, motion, bad):
+@pytest.mark.parametrize("H,N,motion,bad,ticks", [(20, 5, "angular", (), 1), (3, 60, "angular", (2, 5), 1), (3, 60, "linear", (), 3),
+                                                  (1, 80, "angular", (0, 3), 2), (20, 3, "linear", (), 2)])
+def test_free_step_predictions_hold(H, N, motion, bad, ticks):
     """lsq's free step (lsq_spmd.hpp, MPC_QP_FREE_STEP): where the unconstrained step x = e^-1 f satisfies every row of
     the constraints with a margin, the product returns it without forming the transformed matrix or entering NNLS,
     because the long form would find no positive h and end with that x and zero multipliers.  The checking build of the
     host library (-DMPC_QP_FREE_STEP=2) runs the long form all the same and counts the predictions that did not hold:
-    none may, and most QPs of a solve take the free step (so the test says something)."""
+    none may, and most QPs of a solve take the free step (so the test says something).  ticks > 1: further solves from
+    the shifted solution with the previous control in the smoothness term, the controller's warm start."""
     import json
     import os
     import subprocess
@@ -180,7 +181,7 @@ def test_free_step_predictions_hold(H, N, motion, bad):
     from mpc_amd import build
 
     probe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "free_step_probe.py")
-    env = dict(os.environ, MPC_SLSQP_LIB=build.SLSQP_CHECK_LIB_PATH)
+    env = dict(os.environ, MPC_SLSQP_LIB=build.SLSQP_CHECK_LIB_PATH, PROBE_TICKS=str(ticks))
     assert os.path.exists(build.SLSQP_CHECK_LIB_PATH), "python -m mpc_amd.build makes libmpc_slsqp_check.so"
     out = subprocess.run([sys.executable, probe, str(H), str(N), motion] + [str(v) for v in bad], env=env, check=True,
                          capture_output=True, text=True, timeout=600).stdout
