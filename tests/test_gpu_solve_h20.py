@@ -175,3 +175,36 @@ def test_full_size_solves_65536_angular():
     np.testing.assert_array_equal(full.status[sample], want.status)
     lim = np.tile(np.asarray(mp.v_lim), mp.horizon)
     assert np.all(np.abs(full.x) <= lim + 1e-12)             # every converged sequence respects the bounds
+
+
+def test_benchmark_solves_reproduce_the_long_form_hash():
+    """The 62,838 solves of the benchmark's solves leg (BASELINE configs[2]: 65,536 angular-motion scenarios, those past
+    the early exit) with the resident driver: a SHA-256 over every solution, f, iteration count and exit mode.  The value
+    below was computed with the library as it was BEFORE the QP kernel learned to try the unconstrained step first
+    (commit bbd06ce: every QP through the row transform and NNLS) and has been reproduced by every build since
+    (tools/resident_time.py --hash; profiles/r03/experiments/README.md): 1,137,720 QPs, five in six of them now
+    answered by the free step, not one bit different."""
+    import hashlib
+
+    from mpc_amd.batch import MpcContext, ScenarioBatch
+    from mpc_amd.device_solver import ResidentSLSQP
+    from mpc_amd.scenarios import DeviceKinematics, make_scenarios, to_device
+
+    N = 65536
+    mp = MpcParams.reference_yaml_defaults(horizon=20)
+    ctx = MpcContext(mp, N, 0)
+    hs = make_scenarios(mp, DeviceKinematics(ctx), N, motion="angular", cfg_id=3, goal_jitter=0.0)
+    keep = np.nonzero(hs.active)[0]
+    sc_all, _ = to_device(ctx, hs)
+    sc = ctx.gather(sc_all, torch.from_numpy(keep.astype(np.int32)).to(ctx.device),
+                    ScenarioBatch.empty(ctx.device, len(keep), 20, False))
+    x0 = np.tile(hs.u_init, (1, 20))[keep]
+    with ResidentSLSQP(ctx, capacity=len(keep), lanes=1) as dev:
+        r = dev.solve(sc, x0)
+    assert len(keep) == 62838 and int(r.nit.sum()) == 1137720 and r.success.all()
+    h = hashlib.sha256()
+    for a in (r.x, r.fun, r.nit.astype(np.int64), r.status.astype(np.int64)):
+        h.update(np.ascontiguousarray(a).tobytes())
+    assert h.hexdigest() == "df4ca96c8f3255e4a91f489b241c8a948b09cb998d69d185bb76edf6fd1d39d7"
+    assert r.n_free_steps > 0.8 * r.n_qp
+
